@@ -1,0 +1,121 @@
+"""Pins the oracle's primitives: published constants, the reference's literal KATs, and
+definition-level cross-checks (naive DFT, double-and-add)."""
+import hashlib
+
+import pytest
+
+from oracle import fields as F, curve as C, transcript as T
+from oracle.ntt import Domain, dft_naive
+from helpers import field_elems, digest, unhex_point
+
+
+def test_published_field_constants():
+    # SURVEY.md section 8c (ark-bn254 / ark-bls12-381 0.3 FftParameters / FpParameters)
+    assert F.BN254_FR.two_adic_root == 19103219067921713944291392827692070036145651957329286315305642004821462161904
+    assert F.BLS12_381_FR.two_adic_root == 10238227357739495823651030575849232062558860180284477541189508159991286009131
+    assert F.BN254_FR.R == 0x0e0a77c19a07df2f666ea36f7879462e36fc76959f60cd29ac96341c4ffffffb
+    assert F.BN254_FR.inv64 == 0xc2e1f593efffffff
+    assert F.BLS12_381_FR.R == 0x1824b159acc5056f998c4fefecbc4ff55884b7fa0003480200000001fffffffe
+    assert F.BLS12_381_FR.inv64 == 0xfffffffeffffffff
+    for f in (F.BN254_FR, F.BLS12_381_FR):
+        w = f.two_adic_root
+        assert pow(w, 1 << f.two_adicity, f.p) == 1 and pow(w, 1 << (f.two_adicity - 1), f.p) == f.p - 1
+
+
+@pytest.mark.parametrize("f", [F.BN254_FR, F.BLS12_381_FR])
+def test_k1_k2_cosets(f):
+    # plonk-core/src/permutation/constants.rs:36-50 test_constants
+    n = 1 << f.two_adicity
+    assert pow(F.K1, n, f.p) != 1
+    assert pow(F.K1 * f.inv(F.K2), n, f.p) != 1
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381])
+def test_curve_generators(cv):
+    G = C.generator(cv)
+    assert C.is_on_curve(cv, G)
+    assert C.scalar_mul(cv, cv.fr.p, G) is None or C.scalar_mul(cv, cv.fr.p - 1, G) == C.neg(cv, G)
+    assert C.add(cv, C.scalar_mul(cv, cv.fr.p - 1, G), G) is None
+    assert C.scalar_mul(cv, 5, G) == C.add(cv, C.double(cv, C.double(cv, G)), G)
+
+
+def test_keccak_against_hashlib():
+    for m in (b"", b"abc", bytes(range(256)) * 3):
+        assert T.sha3_256(m) == hashlib.sha3_256(m).digest()
+
+
+def test_merlin_conformance_vector():
+    # merlin's published cross-implementation vector ("test protocol" / "some label" / "some data")
+    t = T.Merlin(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == \
+        "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_ethereum_transcript_reference_kat():
+    # gadgets/src/transcript.rs:101-127 (the reference's only byte-level KAT)
+    e = T.EthereumTranscript(F.BN254, "test")
+    e.append_u64("a", 1)
+    assert e.challenge_scalar("a").to_bytes(32, "big").hex() == \
+        "0f9d11cec4f06b0d18060cde3db4196495ddfbb096108951446fc8a1d45f4b59"
+    e.append_scalar("b", 2)
+    assert e.challenge_scalar("b").to_bytes(32, "big").hex() == \
+        "0f4dccb919a5dba2dd010a562ba45b4551291f5e565706536e78b24ac8b5c64d"
+    e.append_commitment("c", (3, 4))
+    assert e.challenge_scalar("c").to_bytes(32, "big").hex() == \
+        "1b5bf46adfcd1dd4f9ac7166586cf83f261192bc4b83fdda30ddee22f9054c1f"
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381])
+def test_ntt_against_definition_and_golden(cv, golden):
+    f = cv.fr
+    for n in (1, 2, 8, 32):
+        d = Domain(f, n)
+        x = field_elems(f.p, 77 + n, n)
+        assert d.fft(x) == dft_naive(f, x, n, d.group_gen)
+        assert d.ifft(d.fft(x)) == x
+        g = f.generator
+        assert d.coset_fft(x) == dft_naive(f, [c * pow(g, i, f.p) % f.p for i, c in enumerate(x)], n, d.group_gen)
+        assert d.coset_ifft(d.coset_fft(x)) == x
+    for e in golden[cv.name]["ntt"]:
+        d = Domain(f, e["n"])
+        x = field_elems(f.p, e["seed"], e["in_len"])
+        for k, fn in (("fft", d.fft), ("ifft", d.ifft), ("coset_fft", d.coset_fft), ("coset_ifft", d.coset_ifft)):
+            y = fn(x)
+            assert digest(y) == e[k + "_sha256"]
+            if k in e:
+                assert [int(v, 16) for v in e[k]] == y
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381])
+def test_msm_golden_small(cv, golden):
+    g = golden[cv.name]
+    tau = int(g["tau"], 16)
+    srs = C.srs_powers(cv, tau, 33)
+    assert [unhex_point(p) for p in g["srs_first"]] == srs[:4]
+    for e in g["msm"]:
+        if e["n"] > 33:
+            continue
+        sc = [int(s, 16) for s in e["scalars"]]
+        assert C.msm_pippenger(cv, srs[:e["n"]], sc) == unhex_point(e["result"])
+        assert C.msm_naive(cv, srs[:e["n"]], sc) == unhex_point(e["result"])
+
+
+def test_msm_window_rule():
+    # c = 11/14/15/15/17 for n = 2^14/18/19/20/22; 3 below 32
+    assert [C.msm_window_bits(1 << k) for k in (14, 18, 19, 20, 22)] == [11, 14, 15, 15, 17]
+    assert C.msm_window_bits(31) == 3 and C.msm_window_bits(32) == 5
+    assert C.msm_reference_adds(1 << 20, 254) == 17 * (1 << 20) + 17 * 2 * 32767
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381])
+def test_point_serialization_roundtrip(cv):
+    G = C.generator(cv)
+    for k in (1, 2, 3, 12345, cv.fr.p - 1):
+        P_ = C.scalar_mul(cv, k, G)
+        b = C.point_serialize_compressed(cv, P_)
+        assert len(b) == (32 if cv.name == "bn254" else 48)
+        assert C.point_deserialize_compressed(cv, b) == P_
+    z = C.point_serialize_compressed(cv, None)
+    assert z[-1] == 0x40 and C.point_deserialize_compressed(cv, z) is None
+    assert len(C.point_to_bytes_uncompressed(cv, G)) == (65 if cv.name == "bn254" else 97)
