@@ -1,0 +1,97 @@
+/*
+ * zkt_plonk.h -- C-ABI of the MI355X (gfx950) prover hot path for ZKTLabs/zkt-plonk.
+ *
+ * The reference is pure Rust and has no FFI; the two generic seams of
+ * ZKTPlonk<F, D, PC, T, C, TABLE_SIZE> (plonk-core/src/plonk.rs:39-52) are where a replacement
+ * plugs in.  Each entry point below names the reference interface it replaces (file:line relative to
+ * /root/reference).  INTEGRATION.md shows the Rust shim (GpuDomain<F>, GpuKZG10<E>, prove_gpu)
+ * that binds them.
+ *
+ * Conventions:
+ *  - Field elements cross as little-endian u64 limbs in MONTGOMERY form, exactly arkworks'
+ *    in-memory representation (ark-ff 0.3 Fp256 / Fp384): Fr = 4 limbs for both curves,
+ *    Fq = 4 limbs (BN254) or 6 limbs (BLS12-381).
+ *  - A G1 affine point crosses as x limbs || y limbs; the all-zero pair (0, 0) encodes the point at
+ *    infinity (GroupAffine is repr(Rust): the shim repacks explicitly, it never transmutes).
+ *  - The caller owns every host buffer; pointers are borrowed for the duration of the call.
+ *    Entry points with the _dev suffix take DEVICE pointers (HBM resident, same layout) and enqueue
+ *    on the context's stream without synchronising.
+ *  - Every call returns ZKT_OK or an error code; zkt_last_error() gives the message.  Nothing
+ *    aborts: where the reference panics (zero denominators, equal challenges, short quotient) the
+ *    library reports an error.
+ *  - A context is used by one thread at a time; several contexts may coexist.
+ */
+#ifndef ZKT_PLONK_H
+#define ZKT_PLONK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkt_ctx zkt_ctx;
+
+enum {
+    ZKT_CURVE_BN254 = 0,     /* ark-bn254 0.3    (bin/src/instance.rs:7-10)  */
+    ZKT_CURVE_BLS12_381 = 1  /* ark-bls12-381 0.3 (bin/src/instance.rs:12-15) */
+};
+
+enum {
+    ZKT_OK = 0,
+    ZKT_ERR_INVALID_ARGUMENT = 1,
+    ZKT_ERR_INVALID_DOMAIN_SIZE = 2,   /* Error::InvalidEvalDomainSize, plonk-core/src/error.rs */
+    ZKT_ERR_HIP = 3,
+    ZKT_ERR_NO_DEVICE = 4,
+    ZKT_ERR_TOO_MANY_COEFFICIENTS = 5, /* kzg10 Error::TooManyCoefficients -> Error::PCError     */
+    ZKT_ERR_ZERO_DENOMINATOR = 6,      /* reference: .inverse().unwrap() panics                   */
+    ZKT_ERR_EQUAL_CHALLENGES = 7,      /* reference: assert_ne! at prove.rs:202-207               */
+    ZKT_ERR_NOT_IN_TABLE = 8,          /* Error::ElementNotIndexedInTable, multiset.rs:121        */
+    ZKT_ERR_QUOTIENT_TOO_SHORT = 9,    /* reference: slice panic at prove.rs:287-300              */
+    ZKT_ERR_NOT_LOADED = 10
+};
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Creates a context on HIP device `device_id` for `curve_id`.  Fails with ZKT_ERR_NO_DEVICE when no
+ * GPU is present: there is no CPU fallback. */
+int zkt_ctx_create(int curve_id, int device_id, zkt_ctx** out);
+void zkt_ctx_destroy(zkt_ctx* ctx);
+const char* zkt_last_error(const zkt_ctx* ctx);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream) for every launch of this context. */
+int zkt_ctx_set_stream(zkt_ctx* ctx, void* hip_stream);
+int zkt_ctx_synchronize(zkt_ctx* ctx);
+const char* zkt_version(void);
+
+/* ---- device memory helpers (plumbing for callers without their own allocator) -------------- */
+int zkt_dev_alloc(zkt_ctx* ctx, size_t bytes, void** dptr);
+int zkt_dev_free(zkt_ctx* ctx, void* dptr);
+int zkt_dev_upload(zkt_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int zkt_dev_download(zkt_ctx* ctx, void* host, const void* dptr, size_t bytes);
+
+/* ---- Domain seam: D: EvaluationDomain<F> + EvaluationDomainExt<F> (prove.rs:70) ------------ */
+/* Radix-2 transform of size 2^log_n over Fr, natural order in and out.
+ *   inverse = 0, coset = 0 : D::fft            (util.rs:104-113)  out[i] = sum_j in[j] w^(ij)
+ *   inverse = 1, coset = 0 : D::ifft(_in_place) (util.rs:63-86)   inverse, scaled by 1/n
+ *   inverse = 0, coset = 1 : D::coset_fft(_in_place) (util.rs:117-140)  in[j] *= g^j first
+ *   inverse = 1, coset = 1 : D::coset_ifft_in_place (util.rs:90-100)    then out[j] *= g^-j
+ * `in` holds in_len <= 2^log_n elements and is zero-padded (ark-poly resizes the coefficient vector);
+ * `out` receives 2^log_n elements.  in == out is allowed.  log_n > TWO_ADICITY (28 / 32) or
+ * in_len > 2^log_n -> ZKT_ERR_INVALID_DOMAIN_SIZE. */
+int zkt_ntt(zkt_ctx* ctx, int log_n, int inverse, int coset, const uint64_t* in, size_t in_len, uint64_t* out);
+int zkt_ntt_dev(zkt_ctx* ctx, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out);
+/* EvaluationDomainExt::group_gen (util.rs:52-58): writes the 2^log_n-th root of unity (4 limbs). */
+int zkt_domain_group_gen(zkt_ctx* ctx, int log_n, uint64_t* out4);
+
+/* ---- debug / test support ------------------------------------------------------------------ */
+/* Dumps the compiled-in parameter tables (modulus, -p^-1 mod 2^32, R, R^2) as u32 words for
+ * which = 0 (Fr) or 1 (Fq) of the context's curve; returns the limb count. */
+int zkt_debug_params(zkt_ctx* ctx, int which, uint32_t* out, size_t out_words);
+/* Elementwise Fr product on the device (out[i] = a[i]*b[i], Montgomery); test hook for the field
+ * kernels. Host pointers. */
+int zkt_debug_fr_mul(zkt_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKT_PLONK_H */

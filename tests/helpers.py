@@ -31,3 +31,12 @@ def digest(vals):
 
 def unhex_point(p):
     return None if p is None else (int(p[0], 16), int(p[1], 16))
+
+
+def rand_fr(rng, n):
+    """n valid field elements as (n, 4) uint64 Montgomery words: any value below 2^253 is below both
+    scalar moduli, so random limbs with the top limb < 2^61 are canonical representatives."""
+    import numpy as np
+    x = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    x[:, 3] >>= np.uint64(3)
+    return x

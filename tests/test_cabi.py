@@ -1,0 +1,36 @@
+"""CPU checks of the drop-in boundary: the library loads and exports every symbol the public header
+declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+
+import pytest
+
+import zkt_plonk_amd as z
+
+
+def test_library_exports_every_declared_symbol():
+    L = z.lib()
+    syms = z.declared_symbols()
+    assert "zkt_ntt" in syms and "zkt_ctx_create" in syms
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_version_and_no_cpu_fallback():
+    L = z.lib()
+    assert b"gfx950" in L.zkt_version()
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(z.ZktError) as e:
+            z.Context("bn254")
+        assert e.value.code == 4  # ZKT_ERR_NO_DEVICE: the product never computes on the CPU
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "zkt-plonk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f

@@ -1,0 +1,17 @@
+"""zkt-plonk_amd: MI355X (gfx950) prover hot path for ZKTLabs/zkt-plonk behind a C-ABI.
+
+Host-side mirror of the reference's two generic seams:
+
+* ``GpuDomain``  ~ ``D: EvaluationDomain<F> + EvaluationDomainExt<F>``  (plonk-core/src/util.rs:27-140)
+* ``GpuKZG10``   ~ ``PC: HomomorphicCommitment<F>`` = SonicKZG10 commit/open (plonk-core/src/commitment.rs:24-46)
+* ``prove``      ~ ``proof_system::prove``                                 (plonk-core/src/proof_system/prove.rs:59-470)
+
+All numerics run in ``libzkt_plonk_hip.so`` (hand-written HIP kernels).  There is no CPU fallback:
+importing works without a GPU (so the C-ABI can be inspected), creating a ``Context`` does not.
+"""
+from ._lib import (  # noqa: F401
+    Context, ZktError, lib, lib_path, CURVE_BN254, CURVE_BLS12_381, curve_id, declared_symbols,
+)
+from .domain import GpuDomain  # noqa: F401
+
+__all__ = ["Context", "ZktError", "GpuDomain", "lib", "lib_path", "CURVE_BN254", "CURVE_BLS12_381"]

@@ -1,0 +1,177 @@
+"""ctypes binding of libzkt_plonk_hip.so (the C-ABI declared in include/zkt_plonk.h)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libzkt_plonk_hip.so")
+_HEADER = os.path.join(_HERE, "..", "include", "zkt_plonk.h")
+
+CURVE_BN254 = 0
+CURVE_BLS12_381 = 1
+_CURVES = {"bn254": 0, "bls12_381": 1, "bls12-381": 1, 0: 0, 1: 1}
+
+_lib = None
+
+
+class ZktError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("zkt error %d: %s" % (code, msg))
+        self.code = code
+
+
+def curve_id(curve) -> int:
+    return _CURVES[curve]
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+def declared_symbols():
+    """Every function the public header declares (used by the CPU test that checks the exports)."""
+    text = open(_HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zkt_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Loads the HIP library.  Raises loudly when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError(
+                "libzkt_plonk_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'`; the HIP extension is mandatory, there is no CPU fallback." % _LIB)
+        L = ctypes.CDLL(_LIB)
+        vp, u64p, u32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+        L.zkt_version.restype = ctypes.c_char_p
+        L.zkt_last_error.restype = ctypes.c_char_p
+        L.zkt_last_error.argtypes = [vp]
+        L.zkt_ctx_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+        L.zkt_ctx_destroy.argtypes = [vp]
+        L.zkt_ctx_destroy.restype = None
+        L.zkt_ctx_set_stream.argtypes = [vp, vp]
+        L.zkt_ctx_synchronize.argtypes = [vp]
+        L.zkt_dev_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.zkt_dev_free.argtypes = [vp, vp]
+        L.zkt_dev_upload.argtypes = [vp, vp, vp, ctypes.c_size_t]
+        L.zkt_dev_download.argtypes = [vp, vp, vp, ctypes.c_size_t]
+        L.zkt_ntt.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, ctypes.c_size_t, u64p]
+        L.zkt_ntt_dev.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+        L.zkt_domain_group_gen.argtypes = [vp, ctypes.c_int, u64p]
+        L.zkt_debug_params.argtypes = [vp, ctypes.c_int, u32p, ctypes.c_size_t]
+        L.zkt_debug_fr_mul.argtypes = [vp, u64p, u64p, ctypes.c_size_t, u64p]
+        _bind_optional(L)
+        _lib = L
+    return _lib
+
+
+def _bind_optional(L):
+    vp, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
+    ip = ctypes.POINTER(ctypes.c_int)
+    if hasattr(L, "zkt_srs_load"):
+        L.zkt_srs_load.argtypes = [vp, u64p, ctypes.c_size_t]
+        L.zkt_srs_load_dev.argtypes = [vp, vp, ctypes.c_size_t]
+        L.zkt_srs_generate.argtypes = [vp, u64p, ctypes.c_size_t]
+        L.zkt_srs_download.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, u64p]
+        L.zkt_msm_g1.argtypes = [vp, u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, u64p, ip]
+        L.zkt_msm_g1_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
+
+
+def u64p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need a C-contiguous uint64 array"
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+class Context:
+    """zkt_ctx wrapper: one per caller thread / proof stream."""
+
+    def __init__(self, curve="bn254", device: int = 0):
+        self._L = lib()
+        self.curve = curve_id(curve)
+        self.fq_limbs = 4 if self.curve == CURVE_BN254 else 6
+        h = ctypes.c_void_p()
+        rc = self._L.zkt_ctx_create(self.curve, device, ctypes.byref(h))
+        if rc:
+            raise ZktError(rc, "zkt_ctx_create failed (no GPU? there is no CPU fallback)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.zkt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc:
+            raise ZktError(rc, self._L.zkt_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr: int):
+        self.check(self._L.zkt_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(self._L.zkt_ctx_synchronize(self._h))
+
+    # -- device memory ------------------------------------------------------------------------
+    def alloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self.check(self._L.zkt_dev_alloc(self._h, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, dptr: int):
+        self.check(self._L.zkt_dev_free(self._h, ctypes.c_void_p(dptr)))
+
+    def upload(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self.check(self._L.zkt_dev_upload(self._h, ctypes.c_void_p(dptr), arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+    def download(self, dptr: int, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self.check(self._L.zkt_dev_download(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dptr), out.nbytes))
+        return out
+
+    # -- Domain seam ------------------------------------------------------------------------------
+    def ntt(self, log_n: int, arr: np.ndarray, inverse=False, coset=False) -> np.ndarray:
+        arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty((1 << max(log_n, 0), 4), dtype=np.uint64)
+        self.check(self._L.zkt_ntt(self._h, log_n, int(inverse), int(coset), u64p(arr), arr.shape[0], u64p(out)))
+        return out
+
+    def ntt_dev(self, log_n: int, d_in: int, in_len: int, d_out: int, inverse=False, coset=False):
+        self.check(self._L.zkt_ntt_dev(self._h, log_n, int(inverse), int(coset), ctypes.c_void_p(d_in), in_len,
+                                       ctypes.c_void_p(d_out)))
+
+    def group_gen(self, log_n: int) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        self.check(self._L.zkt_domain_group_gen(self._h, log_n, u64p(out)))
+        return out
+
+    # -- debug hooks ----------------------------------------------------------------------------------
+    def debug_params(self, which: int):
+        buf = (ctypes.c_uint32 * 64)()
+        n = self._L.zkt_debug_params(self._h, which, buf, 64)
+        w = list(buf)
+        to_int = lambda l: sum(int(x) << (32 * i) for i, x in enumerate(l))
+        return dict(p=to_int(w[0:n]), inv32=int(w[n]), r=to_int(w[n + 1:2 * n + 1]), r2=to_int(w[2 * n + 1:3 * n + 1]))
+
+    def debug_fr_mul(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty_like(a)
+        self.check(self._L.zkt_debug_fr_mul(self._h, u64p(a), u64p(b), a.shape[0], u64p(out)))
+        return out

@@ -1,0 +1,210 @@
+// C-ABI entry points: context, memory plumbing, Domain seam (see include/zkt_plonk.h).
+#include "ctx.hpp"
+
+#include <cstring>
+
+namespace zkt {
+
+int set_err(zkt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(zkt_ctx* c, hipError_t e, const char* what) {
+    return set_err(c, ZKT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int dev_alloc(zkt_ctx* c, void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    ZKT_HIP(c, hipMalloc(p, bytes));
+    c->owned.push_back(*p);
+    return ZKT_OK;
+}
+void dev_free(zkt_ctx* c, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < c->owned.size(); ++i)
+        if (c->owned[i] == p) {
+            c->owned[i] = c->owned.back();
+            c->owned.pop_back();
+            (void)hipFree(p);
+            return;
+        }
+}
+int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes) {
+    if (*cur >= bytes && *p) return ZKT_OK;
+    if (*p) {
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        dev_free(c, *p);
+        *p = nullptr;
+        *cur = 0;
+    }
+    int rc = dev_alloc(c, p, bytes);
+    if (rc) return rc;
+    *cur = bytes;
+    return ZKT_OK;
+}
+
+template <class P>
+__global__ void k_fr_mul(const Fe<P>* a, const Fe<P>* b, Fe<P>* o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store<P>(o + i, fe_mul<P>(fe_load<P>(a + i), fe_load<P>(b + i)));
+}
+
+template <class P>
+static int dump_params(uint32_t* out, size_t words) {
+    const int N = P::N;
+    if (words < (size_t)(3 * N + 1)) return -1;
+    for (int i = 0; i < N; ++i) out[i] = P::mod(i);
+    out[N] = P::INV;
+    for (int i = 0; i < N; ++i) out[N + 1 + i] = P::one(i);
+    for (int i = 0; i < N; ++i) out[2 * N + 1 + i] = P::r2(i);
+    return N;
+}
+
+}  // namespace zkt
+
+using namespace zkt;
+
+extern "C" {
+
+const char* zkt_version(void) { return "zkt-plonk_amd 0.1 (gfx950)"; }
+
+int zkt_ctx_create(int curve_id, int device_id, zkt_ctx** out) {
+    if (!out) return ZKT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (curve_id != ZKT_CURVE_BN254 && curve_id != ZKT_CURVE_BLS12_381) return ZKT_ERR_INVALID_ARGUMENT;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count)
+        return ZKT_ERR_NO_DEVICE;  // no CPU fallback by design
+    if (hipSetDevice(device_id) != hipSuccess) return ZKT_ERR_NO_DEVICE;
+    zkt_ctx* c = new zkt_ctx();
+    c->curve = curve_id;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ZKT_ERR_HIP;
+    }
+    c->own_stream = true;
+    *out = c;
+    return ZKT_OK;
+}
+
+void zkt_ctx_destroy(zkt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->ntt_plans.clear();
+    c->msm.reset();
+    c->circuit.reset();
+    for (void* p : c->owned) (void)hipFree(p);
+    c->owned.clear();
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* zkt_last_error(const zkt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int zkt_ctx_set_stream(zkt_ctx* c, void* hip_stream) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return ZKT_OK;
+}
+
+int zkt_ctx_synchronize(zkt_ctx* c) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+int zkt_dev_alloc(zkt_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return ZKT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    return dev_alloc(c, dptr, bytes);
+}
+int zkt_dev_free(zkt_ctx* c, void* dptr) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    dev_free(c, dptr);
+    return ZKT_OK;
+}
+int zkt_dev_upload(zkt_ctx* c, void* dptr, const void* host, size_t bytes) {
+    if (!c || (!dptr && bytes) || (!host && bytes)) return ZKT_ERR_INVALID_ARGUMENT;
+    ZKT_HIP(c, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+int zkt_dev_download(zkt_ctx* c, void* host, const void* dptr, size_t bytes) {
+    if (!c || (!dptr && bytes) || (!host && bytes)) return ZKT_ERR_INVALID_ARGUMENT;
+    ZKT_HIP(c, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+int zkt_ntt_dev(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
+    if (!c || !d_out || (!d_in && in_len)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return ntt_run(c, log_n, inverse, coset, d_in, in_len, d_out);
+}
+
+int zkt_ntt(zkt_ctx* c, int log_n, int inverse, int coset, const uint64_t* in, size_t in_len, uint64_t* out) {
+    if (!c || !out || (!in && in_len)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (log_n < 0 || log_n > 27) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize");
+    (void)hipSetDevice(c->device);
+    const size_t n = (size_t)1 << log_n;
+    if (in_len > n) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "more coefficients than the domain size");
+    int rc = ensure_buffer(c, &c->io_a, &c->io_a_bytes, n * 32);
+    if (rc) return rc;
+    if (in_len) ZKT_HIP(c, hipMemcpyAsync(c->io_a, in, in_len * 32, hipMemcpyHostToDevice, c->stream));
+    rc = ntt_run(c, log_n, inverse, coset, c->io_a, in_len, c->io_a);
+    if (rc) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(out, c->io_a, n * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+int zkt_domain_group_gen(zkt_ctx* c, int log_n, uint64_t* out4) {
+    if (!c || !out4) return ZKT_ERR_INVALID_ARGUMENT;
+    if (c->curve == ZKT_CURVE_BN254) {
+        if (log_n < 0 || log_n > Bn254Fr::TWO_ADICITY) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize");
+        Fe<Bn254Fr> w = root_of_unity<Bn254Fr>(log_n);
+        memcpy(out4, w.v, 32);
+    } else {
+        if (log_n < 0 || log_n > Bls381Fr::TWO_ADICITY) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize");
+        Fe<Bls381Fr> w = root_of_unity<Bls381Fr>(log_n);
+        memcpy(out4, w.v, 32);
+    }
+    return ZKT_OK;
+}
+
+int zkt_debug_params(zkt_ctx* c, int which, uint32_t* out, size_t out_words) {
+    if (!c || !out) return -1;
+    if (c->curve == ZKT_CURVE_BN254) return which == 0 ? dump_params<Bn254Fr>(out, out_words) : dump_params<Bn254Fq>(out, out_words);
+    return which == 0 ? dump_params<Bls381Fr>(out, out_words) : dump_params<Bls381Fq>(out, out_words);
+}
+
+int zkt_debug_fr_mul(zkt_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    if (!c || !a || !b || !out) return ZKT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    int rc = ensure_buffer(c, &c->io_a, &c->io_a_bytes, n * 32);
+    if (rc) return rc;
+    rc = ensure_buffer(c, &c->io_b, &c->io_b_bytes, n * 32);
+    if (rc) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(c->io_a, a, n * 32, hipMemcpyHostToDevice, c->stream));
+    ZKT_HIP(c, hipMemcpyAsync(c->io_b, b, n * 32, hipMemcpyHostToDevice, c->stream));
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (c->curve == ZKT_CURVE_BN254)
+        hipLaunchKernelGGL(k_fr_mul<Bn254Fr>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<Bn254Fr>*)c->io_a,
+                           (const Fe<Bn254Fr>*)c->io_b, (Fe<Bn254Fr>*)c->io_a, n);
+    else
+        hipLaunchKernelGGL(k_fr_mul<Bls381Fr>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<Bls381Fr>*)c->io_a,
+                           (const Fe<Bls381Fr>*)c->io_b, (Fe<Bls381Fr>*)c->io_a, n);
+    ZKT_HIP(c, hipGetLastError());
+    ZKT_HIP(c, hipMemcpyAsync(out, c->io_a, n * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+}  // extern "C"

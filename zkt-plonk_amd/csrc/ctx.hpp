@@ -1,0 +1,66 @@
+// Library context: one per caller thread / proof stream (SURVEY.md section 8b "Threading").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+#include <memory>
+
+#include "../../include/zkt_plonk.h"
+#include "fp.hpp"
+#include "ntt.hpp"
+
+namespace zkt {
+
+struct MsmState;      // msm.hip
+struct CircuitState;  // prover.hip
+
+}  // namespace zkt
+
+struct zkt_ctx {
+    int curve = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // NTT plans keyed by (log_n, inverse, coset); tables live in HBM for the ctx lifetime.
+    std::map<std::tuple<int, int, int>, std::shared_ptr<void>> ntt_plans;
+    // scratch (grown on demand, never shrunk)
+    void* ntt_scratch = nullptr;
+    size_t ntt_scratch_bytes = 0;
+    void* io_a = nullptr;
+    size_t io_a_bytes = 0;
+    void* io_b = nullptr;
+    size_t io_b_bytes = 0;
+
+    std::shared_ptr<zkt::MsmState> msm;
+    std::shared_ptr<zkt::CircuitState> circuit;
+    std::vector<void*> owned;  // every hipMalloc made on behalf of this ctx
+};
+
+namespace zkt {
+
+int set_err(zkt_ctx* c, int code, const std::string& msg);
+int hip_fail(zkt_ctx* c, hipError_t e, const char* what);
+
+#define ZKT_HIP(c, call)                                        \
+    do {                                                        \
+        hipError_t _e = (call);                                 \
+        if (_e != hipSuccess) return zkt::hip_fail((c), _e, #call); \
+    } while (0)
+
+// grows *p to at least `bytes`
+int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes);
+int dev_alloc(zkt_ctx* c, void** p, size_t bytes);
+void dev_free(zkt_ctx* c, void* p);
+
+// ntt.hip
+template <class P>
+Fe<P> root_of_unity(int log_n);
+int ntt_run(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out);
+
+}  // namespace zkt

@@ -1,0 +1,482 @@
+// NTT kernels + plan construction (see ntt.hpp for the decomposition).
+#include "ctx.hpp"
+
+namespace zkt {
+
+constexpr int TILE_LOG = 10;          // elements per workgroup tile
+constexpr int TILE = 1 << TILE_LOG;   // 1024 x 32 B = 32 KiB of LDS
+constexpr int NTT_THREADS = 128;      // 8 elements per thread
+constexpr int EPT = TILE / NTT_THREADS;
+
+// LDS tile as two 16-byte planes so that consecutive lanes touch consecutive 16-B slots
+// (ds_read_b128 / ds_write_b128 conflict-free for unit-stride columns).
+template <class P>
+ZKT_D Fe<P> lds_get(const uint4* lo, const uint4* hi, int idx) {
+    static_assert(P::N == 8, "scalar fields are 8 x u32");
+    uint4 a = lo[idx], b = hi[idx];
+    Fe<P> r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+template <class P>
+ZKT_D void lds_put(uint4* lo, uint4* hi, int idx, const Fe<P>& x) {
+    lo[idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    hi[idx] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+ZKT_D uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
+
+// One radix-2^G DIF step on 2^G elements held in registers.
+//   level L: block size m = R >> L; element i sits at row blk*m + i*sub + off, sub = m >> G.
+//   sub-level l pairs (i, i + h), h = 2^(G-1-l); twiddle W_R^((i & (h-1))*sub + off) << (L + l)).
+template <class P, int G>
+ZKT_D void dif_group(Fe<P>* x, const Fe<P>* w_inner, int off, int sub, int L) {
+#pragma unroll
+    for (int l = 0; l < G; ++l) {
+        const int h = 1 << (G - 1 - l);
+#pragma unroll
+        for (int i = 0; i < (1 << G); ++i) {
+            if ((i & h) == 0) {
+                Fe<P> u = x[i], v = x[i + h];
+                x[i] = fe_add<P>(u, v);
+                Fe<P> d = fe_sub<P>(u, v);
+                int e = ((i & (h - 1)) * sub + off) << (L + l);
+                // e == 0 only for the last level / first column: keep the multiply uniform
+                x[i + h] = fe_mul<P>(d, fe_load<P>(w_inner + e));
+            }
+        }
+    }
+}
+
+template <class P, int LOG_R, int G, int L>
+ZKT_D void dif_step(uint4* lo, uint4* hi, const Fe<P>* w_inner, int tid) {
+    constexpr int R = 1 << LOG_R;
+    constexpr int T = TILE >> LOG_R;
+    constexpr int m = R >> L;
+    constexpr int sub = m >> G;
+    constexpr int UNITS = EPT >> G;  // independent radix-2^G groups per thread
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        int q = tid * UNITS + u;
+        int c = q % T;
+        int rest = q / T;
+        int off = rest % sub;
+        int blk = rest / sub;
+        int row0 = blk * m + off;
+        Fe<P> x[1 << G];
+#pragma unroll
+        for (int i = 0; i < (1 << G); ++i) x[i] = lds_get<P>(lo, hi, (row0 + i * sub) * T + c);
+        dif_group<P, G>(x, w_inner, off, sub, L);
+#pragma unroll
+        for (int i = 0; i < (1 << G); ++i) lds_put<P>(lo, hi, (row0 + i * sub) * T + c, x[i]);
+    }
+}
+
+template <class P, int LOG_R>
+ZKT_D void dif_all(uint4* lo, uint4* hi, const Fe<P>* w, int tid) {
+    if constexpr (LOG_R == 5) {
+        dif_step<P, 5, 3, 0>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 5, 2, 3>(lo, hi, w, tid);
+    } else if constexpr (LOG_R == 6) {
+        dif_step<P, 6, 3, 0>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 6, 3, 3>(lo, hi, w, tid);
+    } else if constexpr (LOG_R == 7) {
+        dif_step<P, 7, 3, 0>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 7, 3, 3>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 7, 1, 6>(lo, hi, w, tid);
+    } else if constexpr (LOG_R == 8) {
+        dif_step<P, 8, 3, 0>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 8, 3, 3>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 8, 2, 6>(lo, hi, w, tid);
+    } else {
+        static_assert(LOG_R == 9, "unsupported radix");
+        dif_step<P, 9, 3, 0>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 9, 3, 3>(lo, hi, w, tid); __syncthreads();
+        dif_step<P, 9, 3, 6>(lo, hi, w, tid);
+    }
+}
+
+// One pass: R-point transforms of a [R][T] tile.  LAST selects the transposing pass.
+template <class P, int LOG_R, bool LAST>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
+    constexpr int R = 1 << LOG_R;
+    constexpr int LOG_T = TILE_LOG - LOG_R;
+    constexpr int T = 1 << LOG_T;
+    __shared__ uint4 lds_lo[TILE];
+    __shared__ uint4 lds_hi[TILE];
+    __shared__ Fe<P> lds_w[R / 2];
+
+    const int tid = threadIdx.x;
+    const Fe<P>* in = reinterpret_cast<const Fe<P>*>(a.in);
+    Fe<P>* out = reinterpret_cast<Fe<P>*>(a.out);
+    const Fe<P>* w_inner = reinterpret_cast<const Fe<P>*>(a.w_inner);
+    const Fe<P>* in_row = reinterpret_cast<const Fe<P>*>(a.in_row);
+    const Fe<P>* tw = reinterpret_cast<const Fe<P>*>(a.tw);
+    const Fe<P>* out_row = reinterpret_cast<const Fe<P>*>(a.out_row);
+
+    for (int i = tid; i < R / 2; i += NTT_THREADS) lds_w[i] = fe_load<P>(w_inner + i);
+
+    const uint64_t tile = blockIdx.x;
+    uint64_t in_base, out_base, tw_base;
+    uint64_t ld_r, ld_c, st_k;
+    if constexpr (!LAST) {
+        // position = hi*(R*S) + r*S + lo ; tile = T consecutive lo
+        const uint32_t log_s = a.log_s;
+        const uint64_t tiles_per_hi = (uint64_t)1 << (log_s - LOG_T);
+        const uint64_t hi = tile >> (log_s - LOG_T);
+        const uint64_t lo0 = (tile & (tiles_per_hi - 1)) << LOG_T;
+        in_base = (hi << (LOG_R + log_s)) + lo0;
+        out_base = in_base;
+        ld_r = (uint64_t)1 << log_s;
+        ld_c = 1;
+        st_k = ld_r;
+        tw_base = hi << LOG_R;  // row-shared: tw[hi*R + r]
+    } else {
+        // input [k1][mid][r] ; tile = T consecutive k1 for one mid ; output k1 + R1*mid + (N/R)*k
+        const uint32_t log_r1 = a.log_r1, log_mid = a.log_mid;
+        const uint64_t k1_tiles = (uint64_t)1 << (log_r1 - LOG_T);
+        const uint64_t mid = tile >> (log_r1 - LOG_T);
+        const uint64_t k10 = (tile & (k1_tiles - 1)) << LOG_T;
+        in_base = (k10 << (log_mid + LOG_R)) + (mid << LOG_R);
+        ld_r = 1;
+        ld_c = (uint64_t)1 << (log_mid + LOG_R);
+        out_base = k10 + (mid << log_r1);
+        st_k = (uint64_t)1 << (a.log_n - LOG_R);
+        tw_base = (k10 + (mid << log_r1)) << LOG_R;  // tile-shaped: tw[(K0 + c)*R + r]
+    }
+
+    // ---- load (coalesced along the contiguous axis), fused input scaling ----
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        int flat = e * NTT_THREADS + tid;
+        int r, c;
+        if constexpr (!LAST) {
+            c = flat & (T - 1);
+            r = flat >> LOG_T;
+        } else {
+            r = flat & (R - 1);
+            c = flat >> LOG_R;
+        }
+        uint64_t g = in_base + (uint64_t)r * ld_r + (uint64_t)c * ld_c;
+        Fe<P> x = (g < a.in_len) ? fe_load<P>(in + g) : fe_zero<P>();
+        if (in_row) x = fe_mul<P>(x, fe_load<P>(in_row + r));
+        if (tw) {
+            uint64_t ti = LAST ? (tw_base + ((uint64_t)c << LOG_R) + r) : (tw_base + r);
+            x = fe_mul<P>(x, fe_load<P>(tw + ti));
+        }
+        lds_put<P>(lds_lo, lds_hi, r * T + c, x);
+    }
+    __syncthreads();
+
+    dif_all<P, LOG_R>(lds_lo, lds_hi, lds_w, tid);
+    __syncthreads();
+
+    // ---- store: row rho of the tile holds frequency bitrev(rho) ----
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        int flat = e * NTT_THREADS + tid;
+        int c = flat & (T - 1);
+        int k = flat >> LOG_T;
+        int rho = (int)bitrev32((uint32_t)k, LOG_R);
+        Fe<P> x = lds_get<P>(lds_lo, lds_hi, rho * T + c);
+        if (out_row) x = fe_mul<P>(x, fe_load<P>(out_row + k));
+        fe_store<P>(out + out_base + (uint64_t)k * st_k + c, x);
+    }
+}
+
+// Whole transform in one workgroup for n <= 1024 (plumbing sizes; not a performance path).
+template <class P>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_small(const Fe<P>* in, uint64_t in_len, Fe<P>* out, int log_n,
+                                                           const Fe<P>* w, const Fe<P>* in_scale,
+                                                           const Fe<P>* out_scale) {
+    __shared__ Fe<P> buf[TILE];
+    const int n = 1 << log_n;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += NTT_THREADS) {
+        Fe<P> x = ((uint64_t)i < in_len) ? fe_load<P>(in + i) : fe_zero<P>();
+        if (in_scale) x = fe_mul<P>(x, fe_load<P>(in_scale + i));
+        buf[i] = x;
+    }
+    __syncthreads();
+    for (int s = 0; s < log_n; ++s) {
+        const int m = n >> s, half = m >> 1;
+        for (int idx = tid; idx < n / 2; idx += NTT_THREADS) {
+            int blk = idx / half, j = idx % half;
+            int i0 = blk * m + j, i1 = i0 + half;
+            Fe<P> u = buf[i0], v = buf[i1];
+            buf[i0] = fe_add<P>(u, v);
+            buf[i1] = fe_mul<P>(fe_sub<P>(u, v), fe_load<P>(w + ((size_t)j << s)));
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < n; k += NTT_THREADS) {
+        Fe<P> x = buf[log_n ? bitrev32((uint32_t)k, log_n) : 0];
+        if (out_scale) x = fe_mul<P>(x, fe_load<P>(out_scale + k));
+        fe_store<P>(out + k, x);
+    }
+}
+
+// ---- table generation (once per plan) ------------------------------------------------------
+// out[i] = scale * base^i
+template <class P>
+__global__ void k_gen_pow(Fe<P>* out, uint64_t n, Fe<P> base, Fe<P> scale) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store<P>(out + i, fe_mul<P>(scale, fe_pow_u64<P>(base, i)));
+}
+// out[K*cols + m] = scale * w^(m*K) * row_base^K * col_base^m
+template <class P>
+__global__ void k_gen_tw2d(Fe<P>* out, uint64_t rows, uint32_t log_cols, Fe<P> w, Fe<P> row_base, Fe<P> col_base,
+                           Fe<P> scale, int use_row, int use_col) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (rows << log_cols)) return;
+    uint64_t K = i >> log_cols, m = i & (((uint64_t)1 << log_cols) - 1);
+    Fe<P> x = fe_mul<P>(scale, fe_pow_u64<P>(w, m * K));
+    if (use_row) x = fe_mul<P>(x, fe_pow_u64<P>(row_base, K));
+    if (use_col) x = fe_mul<P>(x, fe_pow_u64<P>(col_base, m));
+    fe_store<P>(out + i, x);
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+template <class P>
+static Fe<P> host_pow_limbs(const Fe<P>& a, const uint32_t* e, int nlimbs) {
+    Fe<P> r = fe_one<P>();
+    bool started = false;
+    for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+        if (started) r = fe_sqr<P>(r);
+        if ((e[i / 32] >> (i % 32)) & 1u) {
+            r = fe_mul<P>(r, a);
+            started = true;
+        }
+    }
+    return r;
+}
+
+// FftField::get_root_of_unity(2^log_n) (ark-ff 0.3), Montgomery form
+template <class P>
+Fe<P> root_of_unity(int log_n) {
+    uint32_t e[P::N];
+    for (int i = 0; i < P::N; ++i) e[i] = P::mod(i);
+    e[0] -= 1;  // p - 1 (p odd)
+    for (int k = 0; k < P::TWO_ADICITY; ++k)
+        for (int i = 0; i < P::N; ++i) e[i] = (e[i] >> 1) | (i + 1 < P::N ? (e[i + 1] << 31) : 0u);
+    Fe<P> w = host_pow_limbs<P>(fe_from_u32<P>(P::GENERATOR), e, P::N);
+    for (int k = 0; k < P::TWO_ADICITY - log_n; ++k) w = fe_sqr<P>(w);
+    return w;
+}
+template Fe<Bn254Fr> root_of_unity<Bn254Fr>(int);
+template Fe<Bls381Fr> root_of_unity<Bls381Fr>(int);
+
+static void split_log_n(int log_n, int* npass, int* lr) {
+    if (log_n <= TILE_LOG) {
+        *npass = 0;
+        return;
+    }
+    int p = log_n <= 16 ? 2 : 3;
+    *npass = p;
+    int base = log_n / p, rem = log_n % p;
+    for (int i = 0; i < p; ++i) lr[i] = base + (i < rem ? 1 : 0);
+}
+
+template <class P>
+struct PlanHolder {
+    NttPlan<P> plan;
+    zkt_ctx* ctx;
+    ~PlanHolder() {}
+};
+
+template <class P>
+static int alloc_table(zkt_ctx* c, NttPlan<P>& pl, void** p, size_t count) {
+    int rc = dev_alloc(c, p, count * sizeof(Fe<P>));
+    if (rc) return rc;
+    pl.table_bytes += count * sizeof(Fe<P>);
+    return 0;
+}
+
+template <class P>
+static int gen_pow(zkt_ctx* c, void* out, uint64_t n, const Fe<P>& base, const Fe<P>& scale) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_gen_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (Fe<P>*)out, n, base, scale);
+    ZKT_HIP(c, hipGetLastError());
+    return 0;
+}
+template <class P>
+static int gen_tw2d(zkt_ctx* c, void* out, uint64_t rows, uint32_t log_cols, const Fe<P>& w, const Fe<P>* row_base,
+                    const Fe<P>* col_base, const Fe<P>& scale) {
+    uint64_t total = rows << log_cols;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    Fe<P> one = fe_one<P>();
+    hipLaunchKernelGGL(k_gen_tw2d<P>, dim3(blocks), dim3(256), 0, c->stream, (Fe<P>*)out, rows, log_cols, w,
+                       row_base ? *row_base : one, col_base ? *col_base : one, scale, row_base ? 1 : 0,
+                       col_base ? 1 : 0);
+    ZKT_HIP(c, hipGetLastError());
+    return 0;
+}
+
+template <class P>
+static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>& pl) {
+    pl.log_n = log_n;
+    pl.inverse = inverse;
+    pl.coset = coset;
+    split_log_n(log_n, &pl.npass, pl.log_r);
+    const uint64_t N = (uint64_t)1 << log_n;
+    Fe<P> w = root_of_unity<P>(log_n);
+    if (inverse) w = fe_inv<P>(w);
+    Fe<P> g = fe_from_u32<P>(P::GENERATOR);
+    Fe<P> ginv = fe_inv<P>(g);
+    Fe<P> one = fe_one<P>();
+    Fe<P> ninv = one;
+    if (inverse) {
+        Fe<P> nn = fe_zero<P>();
+        nn.v[0] = (uint32_t)(N & 0xffffffffu);
+        nn.v[1] = (uint32_t)(N >> 32);
+        ninv = fe_inv<P>(fe_to_mont<P>(nn));
+    }
+    int rc;
+    if (pl.npass == 0) {
+        if (log_n >= 1) {
+            if ((rc = alloc_table(c, pl, &pl.small_w, N / 2))) return rc;
+            if ((rc = gen_pow<P>(c, pl.small_w, N / 2, w, one))) return rc;
+        }
+        if (!inverse && coset) {
+            if ((rc = alloc_table(c, pl, &pl.small_in, N))) return rc;
+            if ((rc = gen_pow<P>(c, pl.small_in, N, g, one))) return rc;
+        }
+        if (inverse) {
+            if ((rc = alloc_table(c, pl, &pl.small_out, N))) return rc;
+            if ((rc = gen_pow<P>(c, pl.small_out, N, coset ? ginv : one, ninv))) return rc;
+        }
+        return 0;
+    }
+    const int p = pl.npass;
+    // inner twiddles W_R = w^(N/R)
+    for (int i = 0; i < p; ++i) {
+        int lr = pl.log_r[i];
+        Fe<P> wr = fe_pow_u64<P>(w, N >> lr);
+        if ((rc = alloc_table(c, pl, &pl.w_inner[i], (size_t)1 << (lr - 1)))) return rc;
+        if ((rc = gen_pow<P>(c, pl.w_inner[i], (uint64_t)1 << (lr - 1), wr, one))) return rc;
+    }
+    // strides of the input digits: S_i = N / (R_1..R_i)
+    uint64_t S[3];
+    {
+        int acc = 0;
+        for (int i = 0; i < p; ++i) {
+            acc += pl.log_r[i];
+            S[i] = N >> acc;
+        }
+    }
+    if (!inverse && coset) {
+        // pass-1 input row scale g^(n1*S1)
+        Fe<P> gs = fe_pow_u64<P>(g, S[0]);
+        if ((rc = alloc_table(c, pl, &pl.in_row, (size_t)1 << pl.log_r[0]))) return rc;
+        if ((rc = gen_pow<P>(c, pl.in_row, (uint64_t)1 << pl.log_r[0], gs, one))) return rc;
+    }
+    // boundary tables tw[i] (consumed by pass i): rows K_i < P_i, cols n_{i+1} < R_{i+1};
+    //   entry = w_{P_{i+1}}^(n*K) * [forward coset: g^(n*S_{i+1})] * [last, inverse: N^-1 * (coset: g^-K)]
+    int acc = 0;
+    for (int i = 1; i < p; ++i) {
+        acc += pl.log_r[i - 1];
+        uint64_t rows = (uint64_t)1 << acc;           // P_i
+        uint32_t log_cols = pl.log_r[i];              // R_{i+1}
+        Fe<P> wp = fe_pow_u64<P>(w, N >> (acc + log_cols));  // w_{P_{i+1}}
+        bool last = (i == p - 1);
+        Fe<P> col_base, row_base, scale = one;
+        const Fe<P>* colp = nullptr;
+        const Fe<P>* rowp = nullptr;
+        if (!inverse && coset) {
+            col_base = fe_pow_u64<P>(g, S[i]);
+            colp = &col_base;
+        }
+        if (inverse && last) {
+            scale = ninv;
+            if (coset) {
+                row_base = ginv;
+                rowp = &row_base;
+            }
+        }
+        if ((rc = alloc_table(c, pl, &pl.tw[i], (size_t)(rows << log_cols)))) return rc;
+        if ((rc = gen_tw2d<P>(c, pl.tw[i], rows, log_cols, wp, rowp, colp, scale))) return rc;
+    }
+    if (inverse && coset) {
+        // last-pass output row scale g^-(P_{p-1} * k_p)
+        uint64_t Pm = N >> pl.log_r[p - 1];
+        Fe<P> gp = fe_pow_u64<P>(ginv, Pm);
+        if ((rc = alloc_table(c, pl, &pl.out_row, (size_t)1 << pl.log_r[p - 1]))) return rc;
+        if ((rc = gen_pow<P>(c, pl.out_row, (uint64_t)1 << pl.log_r[p - 1], gp, one))) return rc;
+    }
+    return 0;
+}
+
+template <class P, bool LAST>
+static void launch_pass(zkt_ctx* c, int log_r, unsigned blocks, const NttPassArgs& a) {
+    switch (log_r) {
+        case 5: hipLaunchKernelGGL((k_ntt_pass<P, 5, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 6: hipLaunchKernelGGL((k_ntt_pass<P, 6, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 7: hipLaunchKernelGGL((k_ntt_pass<P, 7, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_ntt_pass<P, 8, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((k_ntt_pass<P, 9, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
+    }
+}
+
+template <class P>
+static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
+    if (log_n < 0 || log_n > P::TWO_ADICITY)
+        return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE,
+                       "InvalidEvalDomainSize: log_size_of_group " + std::to_string(log_n) + " exceeds adicity " +
+                           std::to_string(P::TWO_ADICITY));
+    if (log_n > 27) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "domains above 2^27 are not supported");
+    const uint64_t N = (uint64_t)1 << log_n;
+    if (in_len > N) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "more coefficients than the domain size");
+    auto key = std::make_tuple(log_n, inverse ? 1 : 0, coset ? 1 : 0);
+    auto it = c->ntt_plans.find(key);
+    if (it == c->ntt_plans.end()) {
+        auto holder = std::make_shared<NttPlan<P>>();
+        int rc = build_plan<P>(c, log_n, inverse ? 1 : 0, coset ? 1 : 0, *holder);
+        if (rc) return rc;
+        it = c->ntt_plans.emplace(key, std::static_pointer_cast<void>(holder)).first;
+    }
+    const NttPlan<P>& pl = *static_cast<const NttPlan<P>*>(it->second.get());
+    if (pl.npass == 0) {
+        hipLaunchKernelGGL(k_ntt_small<P>, dim3(1), dim3(NTT_THREADS), 0, c->stream, (const Fe<P>*)d_in,
+                           (uint64_t)in_len, (Fe<P>*)d_out, log_n, (const Fe<P>*)pl.small_w,
+                           (const Fe<P>*)pl.small_in, (const Fe<P>*)pl.small_out);
+        ZKT_HIP(c, hipGetLastError());
+        return 0;
+    }
+    int rc = ensure_buffer(c, &c->ntt_scratch, &c->ntt_scratch_bytes, N * sizeof(Fe<P>));
+    if (rc) return rc;
+    const int p = pl.npass;
+    const unsigned blocks = (unsigned)(N >> TILE_LOG);
+    int acc = 0;
+    for (int i = 0; i < p; ++i) {
+        NttPassArgs a{};
+        const bool last = (i == p - 1);
+        a.in = (i == 0) ? d_in : c->ntt_scratch;
+        a.out = last ? d_out : c->ntt_scratch;
+        a.w_inner = pl.w_inner[i];
+        a.in_row = (i == 0) ? pl.in_row : nullptr;
+        a.tw = pl.tw[i];
+        a.out_row = last ? pl.out_row : nullptr;
+        a.in_len = (i == 0) ? (uint64_t)in_len : N;
+        a.log_n = (uint32_t)log_n;
+        acc += pl.log_r[i];
+        if (!last) {
+            a.log_s = (uint32_t)(log_n - acc);
+            launch_pass<P, false>(c, pl.log_r[i], blocks, a);
+        } else {
+            a.log_r1 = (uint32_t)pl.log_r[0];
+            a.log_mid = (uint32_t)(log_n - pl.log_r[0] - pl.log_r[i]);
+            launch_pass<P, true>(c, pl.log_r[i], blocks, a);
+        }
+        ZKT_HIP(c, hipGetLastError());
+    }
+    return 0;
+}
+
+int ntt_run(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
+    if (c->curve == ZKT_CURVE_BN254) return ntt_run_t<Bn254Fr>(c, log_n, inverse, coset, d_in, in_len, d_out);
+    return ntt_run_t<Bls381Fr>(c, log_n, inverse, coset, d_in, in_len, d_out);
+}
+
+}  // namespace zkt
