@@ -83,6 +83,35 @@ int zkt_ntt_dev(zkt_ctx* ctx, int log_n, int inverse, int coset, const void* d_i
 /* EvaluationDomainExt::group_gen (util.rs:52-58): writes the 2^log_n-th root of unity (4 limbs). */
 int zkt_domain_group_gen(zkt_ctx* ctx, int log_n, uint64_t* out4);
 
+/* ---- Commitment seam: PC: HomomorphicCommitment<F> = KZG10<E> (commitment.rs:10-46) --------- */
+/* Loads `count` G1 powers (ck.powers_of_g of SonicKZG10's CommitterKey, produced by PC::trim at
+ * plonk.rs:79-85) and precomputes the window multiples used by the MSM.  One-time per key.  The
+ * prover never uses more than n + 6 powers, so loading n + 8 of the 4n + 1 the reference keeps is
+ * enough.  Replaces nothing at run time: it is the device-resident form of `ck`. */
+int zkt_srs_load(zkt_ctx* ctx, const uint64_t* g1_xy_mont, size_t count);
+int zkt_srs_load_dev(zkt_ctx* ctx, const void* d_g1_xy_mont, size_t count);
+/* Test/bench SRS with a KNOWN trapdoor: powers_of_g[i] = tau^i * G (tau: 4 canonical limbs).
+ * Stands in for PC::setup (ark-poly-commit kzg10 setup), which is out of scope; insecure by design. */
+int zkt_srs_generate(zkt_ctx* ctx, const uint64_t* tau_canonical4, size_t count);
+int zkt_srs_download(zkt_ctx* ctx, size_t offset, size_t count, uint64_t* out_xy_mont);
+/* sum_i scalars[i] * powers_of_g[base_offset + i], affine result (x || y Montgomery limbs, (0,0) and
+ * *out_is_infinity = 1 for the identity).  This is VariableBaseMSM::multi_scalar_mul as called by
+ * kzg10::commit / open_with_witness_polynomial (prove.rs:133-135,178-180,249-251,306-308,373-375,
+ * 381-451): scalars_montgomery = 1 takes polynomial coefficients as they sit in a DensePolynomial
+ * (the into_repr() conversion happens on the device), 0 takes canonical bigints (commitment.rs:36-42).
+ * base_offset mirrors skip_leading_zeros_and_convert_to_bigints (powers_of_g[num_leading_zeros..]).
+ * len + base_offset > loaded powers -> ZKT_ERR_TOO_MANY_COEFFICIENTS; len = 0 -> identity. */
+int zkt_msm_g1(zkt_ctx* ctx, const uint64_t* scalars, size_t len, size_t base_offset, int scalars_montgomery,
+               uint64_t* out_xy_mont, int* out_is_infinity);
+/* Same with the scalars already resident in HBM; the affine result is written to HOST memory
+ * (it feeds the host-side transcript).  Synchronises the stream. */
+int zkt_msm_g1_dev(zkt_ctx* ctx, const void* d_scalars, size_t len, size_t base_offset, int scalars_montgomery,
+                   void* out_xy_mont_host);
+/* Enqueue-only form for benchmarking the device part under HIP events (no host finish, no sync). */
+int zkt_msm_enqueue_dev(zkt_ctx* ctx, const void* d_scalars, size_t len, size_t base_offset, int scalars_montgomery);
+/* Window size c, number of windows and loaded powers of the current SRS (0s when none). */
+int zkt_msm_info(zkt_ctx* ctx, int* window_bits, int* windows, size_t* srs_count);
+
 /* ---- debug / test support ------------------------------------------------------------------ */
 /* Dumps the compiled-in parameter tables (modulus, -p^-1 mod 2^32, R, R^2) as u32 words for
  * which = 0 (Fr) or 1 (Fq) of the context's curve; returns the limb count. */

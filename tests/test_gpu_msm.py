@@ -1,0 +1,137 @@
+"""GPU parity: the HIP KZG/G1 MSM (through the C-ABI) against the CPU oracle and golden fixtures."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fields as F, curve as C, coracle as K
+from helpers import field_elems, unhex_point, rand_fr
+
+CURVES = [F.BN254, F.BLS12_381]
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import zkt_plonk_amd as z
+    c = {cv.name: z.Context(cv.name, 0) for cv in CURVES}
+    yield c
+    for x in c.values():
+        x.close()
+
+
+def _pt(cv, out, inf):
+    return None if inf else K.points_from_mont(cv, out)[0]
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_srs_generate_matches_oracle(cv, ctxs, golden):
+    ctx = ctxs[cv.name]
+    tau = int(golden[cv.name]["tau"], 16)
+    ctx.srs_generate(tau, 600)
+    got = ctx.srs_download(0, 600)
+    want = K.srs_mont(cv, tau, 600)
+    assert np.array_equal(got, want)
+    assert K.points_from_mont(cv, got[:4]) == [unhex_point(p) for p in golden[cv.name]["srs_first"]]
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_msm_golden_vectors(cv, ctxs, golden):
+    ctx = ctxs[cv.name]
+    g = golden[cv.name]
+    tau = int(g["tau"], 16)
+    p = cv.fr.p
+    ctx.srs_load(K.srs_mont(cv, tau, 1000))
+    info = ctx.msm_info()
+    assert info["srs_count"] == 1000 and info["window_bits"] >= 8
+    for e in g["msm"]:
+        n = e["n"]
+        if e["seed"] is None:
+            sc = [int(s, 16) for s in e["scalars"]]
+        else:
+            sc = field_elems(p, e["seed"], n)
+            if n >= 31:
+                sc[0], sc[1], sc[2], sc[5] = 0, 1, p - 1, 0
+        out, inf = ctx.msm(K.fr_to_mont(cv, sc))
+        assert _pt(cv, out, inf) == unhex_point(e["result"]), (cv.name, n)
+        out, inf = ctx.msm(K.ints_to_limbs(sc, 4), montgomery=False)  # canonical-bigint entry (commitment.rs:36-42)
+        assert _pt(cv, out, inf) == unhex_point(e["result"]), (cv.name, n, "canonical")
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_msm_edge_cases(cv, ctxs, golden):
+    import zkt_plonk_amd as z
+    ctx = ctxs[cv.name]
+    tau = int(golden[cv.name]["tau"], 16)
+    p = cv.fr.p
+    srs = K.srs_mont(cv, tau, 300)
+    srs[7] = 0          # a base at infinity is skipped
+    srs[9] = srs[8]     # duplicated base: P + P must take the doubling path
+    ctx.srs_load(srs)
+    pts = K.points_from_mont(cv, srs)
+    # empty input -> identity
+    out, inf = ctx.msm(np.zeros((0, 4), dtype=np.uint64))
+    assert inf and not out.any()
+    # all-zero scalars -> identity
+    out, inf = ctx.msm(np.zeros((300, 4), dtype=np.uint64))
+    assert inf
+    # equal scalars on the duplicated bases, scalar on the infinity base, P + (-P)
+    sc = [0] * 300
+    sc[7], sc[8], sc[9] = 5, 3, 3
+    out, inf = ctx.msm(K.fr_to_mont(cv, sc))
+    assert _pt(cv, out, inf) == C.scalar_mul(cv, 6, pts[8])
+    sc = [0] * 300
+    sc[8], sc[9] = 11, p - 11
+    out, inf = ctx.msm(K.fr_to_mont(cv, sc))
+    assert inf
+    # many identical small scalars (one crowded bucket) and extreme scalars
+    sc = [1] * 300
+    sc[0], sc[1], sc[2] = p - 1, p - 2, (1 << 200) + 12345
+    out, inf = ctx.msm(K.fr_to_mont(cv, sc))
+    want, winf = K.msm_mont(cv, srs, K.fr_to_mont(cv, sc))
+    assert _pt(cv, out, inf) == _pt(cv, want, winf)
+    # base_offset (kzg10 skip_leading_zeros) and the TooManyCoefficients error
+    sc = field_elems(p, 4, 50)
+    out, inf = ctx.msm(K.fr_to_mont(cv, sc), base_offset=100)
+    want, winf = K.msm_mont(cv, srs[100:150], K.fr_to_mont(cv, sc))
+    assert _pt(cv, out, inf) == _pt(cv, want, winf)
+    with pytest.raises(z.ZktError) as e:
+        ctx.msm(np.zeros((301, 4), dtype=np.uint64))
+    assert e.value.code == 5
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n", [10, 14, 16])
+def test_msm_random_matches_oracle(cv, log_n, ctxs):
+    ctx = ctxs[cv.name]
+    n = (1 << log_n) + 5
+    ctx.srs_generate(0xC0FFEE + log_n, n)
+    srs = ctx.srs_download(0, n)
+    rng = np.random.default_rng(log_n)
+    sc = rand_fr(rng, n)
+    sc[::97] = 0                                  # ~1 % zeros
+    sc[1::89] = K.fr_to_mont(cv, [1])[0]          # ~1 % ones
+    out, inf = ctx.msm(sc)
+    want, winf = K.msm_mont(cv, srs, sc)
+    assert not inf and np.array_equal(out, want)
+
+
+def test_msm_full_size_2_20(ctxs):
+    """BASELINE config 3: 2^20 scalars/points, bit-exact commitment (BN254), plus linearity."""
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    n = 1 << 20
+    ctx.srs_generate(0x5EED, n)
+    assert ctx.msm_info()["window_bits"] == 18
+    srs = ctx.srs_download(0, n)
+    rng = np.random.default_rng(2020)
+    a = rand_fr(rng, n)
+    out, inf = ctx.msm(a)
+    want, winf = K.msm_mont(cv, srs, a)
+    assert not inf and np.array_equal(out, want)
+    # linearity: msm(a) + msm(b) == msm(a + b) with b = a shifted (checked with oracle point adds)
+    b = np.roll(a, 1, axis=0)
+    ab = K.fr_to_mont(cv, [(x + y) % cv.fr.p for x, y in zip(K.fr_from_mont(cv, a[:4096]), K.fr_from_mont(cv, b[:4096]))])
+    pa = _pt(cv, *ctx.msm(a[:4096]))
+    pb = _pt(cv, *ctx.msm(b[:4096]))
+    pab = _pt(cv, *ctx.msm(ab))
+    assert C.add(cv, pa, pb) == pab

@@ -82,6 +82,8 @@ def _bind_optional(L):
         L.zkt_srs_download.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, u64p]
         L.zkt_msm_g1.argtypes = [vp, u64p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, u64p, ip]
         L.zkt_msm_g1_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
+        L.zkt_msm_enqueue_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+        L.zkt_msm_info.argtypes = [vp, ip, ip, ctypes.POINTER(ctypes.c_size_t)]
 
 
 def u64p(a: np.ndarray):
@@ -160,6 +162,43 @@ class Context:
         out = np.zeros(4, dtype=np.uint64)
         self.check(self._L.zkt_domain_group_gen(self._h, log_n, u64p(out)))
         return out
+
+    # -- Commitment seam ----------------------------------------------------------------------------
+    def srs_load(self, pts: np.ndarray):
+        pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 2 * self.fq_limbs)
+        self.check(self._L.zkt_srs_load(self._h, u64p(pts), pts.shape[0]))
+
+    def srs_generate(self, tau: int, count: int):
+        t = np.array([(tau >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        self.check(self._L.zkt_srs_generate(self._h, u64p(t), count))
+
+    def srs_download(self, offset: int, count: int) -> np.ndarray:
+        out = np.empty((count, 2 * self.fq_limbs), dtype=np.uint64)
+        self.check(self._L.zkt_srs_download(self._h, offset, count, u64p(out)))
+        return out
+
+    def msm(self, scalars: np.ndarray, base_offset: int = 0, montgomery: bool = True):
+        """-> (xy Montgomery limbs (2*fq_limbs,), is_infinity)"""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(2 * self.fq_limbs, dtype=np.uint64)
+        inf = ctypes.c_int(0)
+        self.check(self._L.zkt_msm_g1(self._h, u64p(scalars), scalars.shape[0], base_offset, int(montgomery),
+                                      u64p(out), ctypes.byref(inf)))
+        return out, bool(inf.value)
+
+    def msm_dev(self, d_scalars: int, n: int, base_offset: int = 0, montgomery: bool = True) -> np.ndarray:
+        out = np.zeros(2 * self.fq_limbs, dtype=np.uint64)
+        self.check(self._L.zkt_msm_g1_dev(self._h, ctypes.c_void_p(d_scalars), n, base_offset, int(montgomery),
+                                          out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def msm_enqueue_dev(self, d_scalars: int, n: int, base_offset: int = 0, montgomery: bool = True):
+        self.check(self._L.zkt_msm_enqueue_dev(self._h, ctypes.c_void_p(d_scalars), n, base_offset, int(montgomery)))
+
+    def msm_info(self):
+        c, w, n = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
+        self.check(self._L.zkt_msm_info(self._h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(n)))
+        return dict(window_bits=c.value, windows=w.value, srs_count=n.value)
 
     # -- debug hooks ----------------------------------------------------------------------------------
     def debug_params(self, which: int):

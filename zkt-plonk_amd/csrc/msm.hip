@@ -1,0 +1,603 @@
+// KZG10 G1 multi-scalar multiplication on gfx950 (row a11 of SURVEY.md section 8).
+//
+// Replaces ark-ec 0.3 VariableBaseMSM::multi_scalar_mul as reached through
+// SonicKZG10::commit / open (plonk-core/src/proof_system/prove.rs:133-135,178-180,249-251,306-308,
+// 373-375,381-451) and HomomorphicCommitment::multi_scalar_mul (plonk-core/src/commitment.rs:32-45).
+// Same group element, different schedule, chosen for HBM capacity and wave-wide execution:
+//
+//  * The SRS is fixed, so at load time every base gets its W = ceil((lambda+1)/c) window multiples
+//    2^(c*w) * P_i precomputed in affine form ([w][i] table in HBM).  All windows then share ONE set
+//    of 2^(c-1) buckets: there is no per-window bucket reduction and no Horner pass over windows.
+//  * Signed c-bit digits halve the bucket count; a negative digit negates y on the fly.
+//  * (bucket, table index) pairs are radix-sorted by bucket; accumulation walks the sorted array in
+//    fixed-size chunks (perfect lane balance whatever the digit distribution), emitting one partial
+//    XYZZ sum per (chunk, bucket) piece at slot chunk + bucket; a second kernel folds a bucket's pieces.
+//  * sum_b b * B_b is computed with short per-thread running sums (segments of 8 buckets), masked
+//    wave/block tree reductions for the segment weights and a final doubling step.
+//  * The single resulting point is normalised (one inversion) on the host, which needs the affine
+//    coordinates for the Fiat-Shamir transcript anyway.
+#include "ctx.hpp"
+#include "ec.hpp"
+
+#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+namespace zkt {
+
+constexpr int MSM_CHUNK = 32;   // sorted entries per accumulation thread
+constexpr int MSM_SEG = 8;      // buckets per running-sum segment
+constexpr int MSM_R2_BLOCKS = 4;
+constexpr int MSM_MAX_Y = 24;
+
+struct MsmState {
+    size_t count = 0;      // bases loaded
+    int c = 0, W = 0;      // window bits, windows
+    uint32_t B = 0;        // buckets = 2^(c-1), ids 1..B
+    void* table = nullptr; // Affine[W][count]
+    // work buffers (sized for n = count)
+    uint32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr;
+    void* cub_tmp = nullptr;
+    size_t cub_bytes = 0;
+    uint32_t* offsets = nullptr;  // B + 2
+    void* pieces = nullptr;       // Xyzz[max_chunks + B + 2]
+    void* buckets = nullptr;      // Xyzz[B + 1]
+    void* segA = nullptr;         // Xyzz[B / SEG]
+    void* segT = nullptr;
+    void* partials = nullptr;     // Xyzz[MAX_Y * R2_BLOCKS]
+    void* result = nullptr;       // Xyzz
+    void* host_result = nullptr;  // pinned
+    ~MsmState() {
+        if (host_result) (void)hipHostFree(host_result);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// SRS: synthetic generation (test / bench trapdoor), window-multiple table
+// ---------------------------------------------------------------------------------------------
+// out[i] = tau^i * G  (insecure test SRS with a known trapdoor; PC::setup is out of scope)
+template <class C>
+__global__ void k_srs_generate(Affine<typename C::Fq>* out, size_t count, Fe<typename C::Fr> tau_mont,
+                               Affine<typename C::Fq> g) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<R> s = fe_from_mont<R>(fe_pow_u64<R>(tau_mont, (uint64_t)i));
+    Xyzz<Q> acc = xyzz_identity<Q>();
+    bool started = false;
+#pragma unroll 1
+    for (int li = R::N - 1; li >= 0; --li) {
+        uint32_t e = s.v[li];
+#pragma unroll 1
+        for (int b = 31; b >= 0; --b) {
+            if (started) acc = xyzz_double<Q>(acc);
+            if ((e >> b) & 1u) {
+                acc = xyzz_add_mixed<Q>(acc, g);
+                started = true;
+            }
+        }
+    }
+    aff_store<Q>(out + i, xyzz_to_affine<Q>(acc));
+}
+
+// table[w][i] = 2^(c*w) * table[0][i]
+template <class C>
+__global__ void k_srs_windows(Affine<typename C::Fq>* table, size_t count, int c, int W) {
+    using Q = typename C::Fq;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Affine<Q> base = aff_load<Q>(table + i);
+    if (aff_is_inf<Q>(base)) {
+        for (int w = 1; w < W; ++w) aff_store<Q>(table + (size_t)w * count + i, base);
+        return;
+    }
+    Xyzz<Q> acc = xyzz_from_affine<Q>(base);
+#pragma unroll 1
+    for (int w = 1; w < W; ++w) {
+#pragma unroll 1
+        for (int k = 0; k < c; ++k) acc = xyzz_double<Q>(acc);
+        Affine<Q> a = xyzz_to_affine<Q>(acc);
+        aff_store<Q>(table + (size_t)w * count + i, a);
+        acc = xyzz_from_affine<Q>(a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// digits
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mont, int c, int W, size_t count,
+                             size_t base_off, uint32_t* keys, uint32_t* vals) {
+    using R = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<R> s = fe_load<R>(scalars + i);
+    if (mont) s = fe_from_mont<R>(s);
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint64_t buf = 0;
+    int bits = 0, w = 0;
+    uint32_t carry = 0;
+    auto emit = [&](uint32_t raw) {
+        uint32_t d = raw + carry, neg = 0;
+        if (d > half) {
+            d = (1u << c) - d;
+            neg = 1u;
+            carry = 1u;
+        } else {
+            carry = 0u;
+        }
+        keys[(size_t)w * n + i] = d;  // 0 = no contribution (bucket 0 is skipped)
+        vals[(size_t)w * n + i] = (uint32_t)((size_t)w * count + base_off + i) | (neg << 31);
+        ++w;
+    };
+#pragma unroll
+    for (int li = 0; li < R::N; ++li) {
+        buf |= (uint64_t)s.v[li] << bits;
+        bits += 32;
+        while (bits >= c && w < W) {
+            emit((uint32_t)buf & mask);
+            buf >>= c;
+            bits -= c;
+        }
+    }
+    while (w < W) {
+        emit((uint32_t)buf & mask);
+        buf >>= c;
+    }
+}
+
+// offsets[b] = first sorted position with key >= b, b in [0, B+1]
+__global__ void k_msm_offsets(const uint32_t* keys, uint32_t m, uint32_t B, uint32_t* offsets) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B + 1) return;
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    offsets[b] = lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulation: fixed-size chunks over the sorted pairs, one piece per (chunk, bucket)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t m,
+                                                        const uint32_t* offsets,
+                                                        const Affine<typename C::Fq>* table,
+                                                        Xyzz<typename C::Fq>* pieces) {
+    using Q = typename C::Fq;
+    const uint32_t base = offsets[1];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = (uint64_t)base + (uint64_t)t * MSM_CHUNK;
+    if (p0 >= m) return;
+    const uint32_t p1 = (uint32_t)((p0 + MSM_CHUNK < m) ? p0 + MSM_CHUNK : m);
+    uint32_t cur = keys[p0];
+    Xyzz<Q> acc = xyzz_identity<Q>();
+    uint32_t v = vals[p0];
+    Affine<Q> pt = aff_load<Q>(table + (v & 0x7fffffffu));
+    for (uint32_t p = (uint32_t)p0; p < p1; ++p) {
+        const uint32_t key = keys[p];
+        const uint32_t vcur = v;
+        const Affine<Q> pcur = pt;
+        if (p + 1 < p1) {  // prefetch the next gathered point behind this addition
+            v = vals[p + 1];
+            pt = aff_load<Q>(table + (v & 0x7fffffffu));
+        }
+        if (key != cur) {
+            xyzz_store<Q>(pieces + (size_t)t + cur, acc);
+            acc = xyzz_identity<Q>();
+            cur = key;
+        }
+        if (!aff_is_inf<Q>(pcur)) {
+            Affine<Q> q = pcur;
+            if (vcur >> 31) q.y = fe_neg<Q>(q.y);
+            acc = xyzz_add_mixed<Q>(acc, q);
+        }
+    }
+    xyzz_store<Q>(pieces + (size_t)t + cur, acc);
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B,
+                                                        const Xyzz<typename C::Fq>* pieces,
+                                                        Xyzz<typename C::Fq>* buckets) {
+    using Q = typename C::Fq;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..B ; bucket 0 is the identity
+    if (b > B) return;
+    Xyzz<Q> acc = xyzz_identity<Q>();
+    if (b >= 1) {
+        const uint32_t base = offsets[1];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        if (e > s) {
+            const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+            acc = xyzz_load<Q>(pieces + (size_t)t0 + b);
+            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xyzz_add<Q>(acc, xyzz_load<Q>(pieces + (size_t)t + b));
+        }
+    }
+    xyzz_store<Q>(buckets + b, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket reduction  S = sum_{b=0..B} b * bucket[b]
+//   = 2^(c-1) * bucket[B] + sum_s A_s + SEG * sum_s s * T_s      (s over segments of SEG buckets)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_segments(const Xyzz<typename C::Fq>* buckets, uint32_t nseg,
+                                                      Xyzz<typename C::Fq>* segA, Xyzz<typename C::Fq>* segT) {
+    using Q = typename C::Fq;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const Xyzz<Q>* a = buckets + (size_t)s * MSM_SEG;
+    Xyzz<Q> run = xyzz_identity<Q>(), acc = xyzz_identity<Q>();
+#pragma unroll 1
+    for (int j = MSM_SEG - 1; j >= 1; --j) {
+        run = xyzz_add<Q>(run, xyzz_load<Q>(a + j));
+        acc = xyzz_add<Q>(acc, run);
+    }
+    run = xyzz_add<Q>(run, xyzz_load<Q>(a));
+    xyzz_store<Q>(segA + s, acc);
+    xyzz_store<Q>(segT + s, run);
+}
+
+template <class Q>
+ZKT_D Xyzz<Q> xyzz_shfl_down(const Xyzz<Q>& p, int delta) {
+    Xyzz<Q> r;
+#pragma unroll
+    for (int i = 0; i < Q::N; ++i) {
+        r.x.v[i] = __shfl_down(p.x.v[i], delta);
+        r.y.v[i] = __shfl_down(p.y.v[i], delta);
+        r.zz.v[i] = __shfl_down(p.zz.v[i], delta);
+        r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta);
+    }
+    return r;
+}
+
+// y = 0: plain sum of segA ; y = k + 1: sum of segT[s] over s with bit k set.  One partial per block.
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::Fq>* segA,
+                                                         const Xyzz<typename C::Fq>* segT, uint32_t nseg,
+                                                         Xyzz<typename C::Fq>* partials) {
+    using Q = typename C::Fq;
+    __shared__ Xyzz<Q> wsum[4];
+    const int y = blockIdx.y;
+    const Xyzz<Q>* src = (y == 0) ? segA : segT;
+    Xyzz<Q> acc = xyzz_identity<Q>();
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
+        if (y == 0 || ((s >> (y - 1)) & 1u)) acc = xyzz_add<Q>(acc, xyzz_load<Q>(src + s));
+    }
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<Q> o = xyzz_shfl_down<Q>(acc, d);
+        acc = xyzz_add<Q>(acc, o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Xyzz<Q> t = wsum[0];
+        for (int i = 1; i < 4; ++i) t = xyzz_add<Q>(t, wsum[i]);
+        xyzz_store<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, t);
+    }
+}
+
+// result = sum_y 2^(e_y) * V_y ; V_y = sum of the y-th row of partials, plus the top bucket with e = c-1
+template <class C>
+__global__ __launch_bounds__(64) void k_msm_final(const Xyzz<typename C::Fq>* partials, int ny, int nblk,
+                                                  const Xyzz<typename C::Fq>* top_bucket, int c,
+                                                  Xyzz<typename C::Fq>* result) {
+    using Q = typename C::Fq;
+    const int y = threadIdx.x;
+    Xyzz<Q> v = xyzz_identity<Q>();
+    int e = 0;
+    if (y < ny) {
+        for (int j = 0; j < nblk; ++j) v = xyzz_add<Q>(v, xyzz_load<Q>(partials + (size_t)y * nblk + j));
+        e = (y == 0) ? 0 : (y - 1) + 3;  // SEG = 8 = 2^3
+    } else if (y == ny) {
+        v = xyzz_load<Q>(top_bucket);
+        e = c - 1;
+    }
+#pragma unroll 1
+    for (int k = 0; k < e; ++k) v = xyzz_double<Q>(v);
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<Q> o = xyzz_shfl_down<Q>(v, d);
+        v = xyzz_add<Q>(v, o);
+    }
+    if (y == 0) xyzz_store<Q>(result, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int floor_log2(size_t x) {
+    int l = 0;
+    while ((x >> (l + 1)) != 0) ++l;
+    return l;
+}
+
+template <class C>
+static int msm_setup(zkt_ctx* c, size_t count) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    auto st = std::make_shared<MsmState>();
+    st->count = count;
+    int lg = floor_log2(count ? count : 1);
+    int cb = lg - 2;
+    if (cb < 8) cb = 8;
+    if (cb > 18) cb = 18;
+    st->c = cb;
+    st->W = (R::BITS + 1 + cb - 1) / cb;
+    st->B = 1u << (cb - 1);
+    if ((uint64_t)st->W * count >= ((uint64_t)1 << 31))
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "SRS too large for 31-bit table indices");
+    int rc;
+    if ((rc = dev_alloc(c, &st->table, (size_t)st->W * count * sizeof(Affine<Q>)))) return rc;
+    size_t m = (size_t)st->W * count;
+    if ((rc = dev_alloc(c, (void**)&st->keys, m * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->keys2, m * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->vals, m * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->vals2, m * 4))) return rc;
+    st->cub_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, st->cub_bytes, st->keys, st->keys2, st->vals, st->vals2, (int)m, 0,
+                                       st->c, c->stream);
+    if ((rc = dev_alloc(c, &st->cub_tmp, st->cub_bytes + 256))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->B + 2) * 4))) return rc;
+    size_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
+    if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(Xyzz<Q>)))) return rc;
+    if ((rc = dev_alloc(c, &st->buckets, ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
+    size_t nseg = st->B / MSM_SEG;
+    if ((rc = dev_alloc(c, &st->segA, nseg * sizeof(Xyzz<Q>)))) return rc;
+    if ((rc = dev_alloc(c, &st->segT, nseg * sizeof(Xyzz<Q>)))) return rc;
+    if ((rc = dev_alloc(c, &st->partials, (size_t)MSM_MAX_Y * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)))) return rc;
+    if ((rc = dev_alloc(c, &st->result, sizeof(Xyzz<Q>)))) return rc;
+    ZKT_HIP(c, hipHostMalloc(&st->host_result, sizeof(Xyzz<Q>)));
+    c->msm = st;
+    return ZKT_OK;
+}
+
+template <class C>
+static int srs_finish(zkt_ctx* c) {
+    using Q = typename C::Fq;
+    MsmState& st = *c->msm;
+    unsigned blocks = (unsigned)((st.count + 127) / 128);
+    hipLaunchKernelGGL(k_srs_windows<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)st.table, st.count, st.c,
+                       st.W);
+    ZKT_HIP(c, hipGetLastError());
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+static void msm_release(zkt_ctx* c) {
+    if (!c->msm) return;
+    MsmState& st = *c->msm;
+    (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {st.table, st.keys, st.keys2, st.vals, st.vals2, st.cub_tmp, st.offsets, st.pieces,
+                    st.buckets, st.segA, st.segT, st.partials, st.result};
+    for (void* p : ptrs) dev_free(c, p);
+    c->msm.reset();
+}
+
+template <class C>
+static int srs_load_t(zkt_ctx* c, const void* src, size_t count, bool src_on_device) {
+    using Q = typename C::Fq;
+    if (count == 0) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "empty SRS");
+    msm_release(c);
+    int rc = msm_setup<C>(c, count);
+    if (rc) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(c->msm->table, src, count * sizeof(Affine<Q>),
+                              src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    return srs_finish<C>(c);
+}
+
+template <class C>
+static Affine<typename C::Fq> generator_mont();
+template <>
+Affine<Bn254Fq> generator_mont<Bn254Curve>() {
+    Affine<Bn254Fq> g;
+    g.x = fe_from_u32<Bn254Fq>(1);
+    g.y = fe_from_u32<Bn254Fq>(2);
+    return g;
+}
+template <>
+Affine<Bls381Fq> generator_mont<Bls381Curve>() {
+    // ark-bls12-381 G1_GENERATOR_X / _Y (canonical limbs), converted to Montgomery form
+    static const uint32_t gx[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                    0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+    static const uint32_t gy[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                    0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+    Affine<Bls381Fq> g;
+    for (int i = 0; i < 12; ++i) {
+        g.x.v[i] = gx[i];
+        g.y.v[i] = gy[i];
+    }
+    g.x = fe_to_mont<Bls381Fq>(g.x);
+    g.y = fe_to_mont<Bls381Fq>(g.y);
+    return g;
+}
+
+template <class C>
+static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    if (count == 0) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "empty SRS");
+    msm_release(c);
+    int rc = msm_setup<C>(c, count);
+    if (rc) return rc;
+    Fe<R> tau;
+    memcpy(tau.v, tau4, 32);
+    tau = fe_to_mont<R>(tau);
+    unsigned blocks = (unsigned)((count + 127) / 128);
+    hipLaunchKernelGGL(k_srs_generate<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)c->msm->table, count, tau,
+                       generator_mont<C>());
+    ZKT_HIP(c, hipGetLastError());
+    return srs_finish<C>(c);
+}
+
+// enqueue the whole MSM; the XYZZ result lands in st.result
+template <class C>
+static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    MsmState& st = *c->msm;
+    const uint32_t m = (uint32_t)((size_t)st.W * n);
+    {
+        unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_msm_digits<C>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<R>*)d_scalars, n, mont,
+                           st.c, st.W, st.count, base_off, st.keys, st.vals);
+        ZKT_HIP(c, hipGetLastError());
+    }
+    size_t tmp = st.cub_bytes;
+    ZKT_HIP(c, hipcub::DeviceRadixSort::SortPairs(st.cub_tmp, tmp, st.keys, st.keys2, st.vals, st.vals2, (int)m, 0,
+                                                  st.c, c->stream));
+    hipLaunchKernelGGL(k_msm_offsets, dim3((st.B + 2 + 255) / 256), dim3(256), 0, c->stream, st.keys2, m, st.B,
+                       st.offsets);
+    ZKT_HIP(c, hipGetLastError());
+    {
+        uint32_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
+        hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.keys2,
+                           st.vals2, m, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
+        ZKT_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
+                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets);
+    ZKT_HIP(c, hipGetLastError());
+    const uint32_t nseg = st.B / MSM_SEG;
+    hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, c->stream,
+                       (const Xyzz<Q>*)st.buckets, nseg, (Xyzz<Q>*)st.segA, (Xyzz<Q>*)st.segT);
+    ZKT_HIP(c, hipGetLastError());
+    int seg_bits = st.c - 1 - 3;  // log2(nseg)
+    int ny = 1 + seg_bits;
+    hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny), dim3(256), 0, c->stream,
+                       (const Xyzz<Q>*)st.segA, (const Xyzz<Q>*)st.segT, nseg, (Xyzz<Q>*)st.partials);
+    ZKT_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, c->stream, (const Xyzz<Q>*)st.partials, ny,
+                       MSM_R2_BLOCKS, (const Xyzz<Q>*)st.buckets + st.B, st.c, (Xyzz<Q>*)st.result);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+
+template <class C>
+static int msm_run_t(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy,
+                     int* out_inf) {
+    using Q = typename C::Fq;
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    MsmState& st = *c->msm;
+    if (base_off > st.count || n > st.count - base_off)
+        return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
+    Affine<Q> res;
+    if (n == 0) {
+        res.x = fe_zero<Q>();
+        res.y = fe_zero<Q>();
+    } else {
+        int rc = msm_enqueue<C>(c, d_scalars, n, base_off, mont);
+        if (rc) return rc;
+        ZKT_HIP(c, hipMemcpyAsync(st.host_result, st.result, sizeof(Xyzz<Q>), hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        Xyzz<Q> r;
+        memcpy(&r, st.host_result, sizeof(r));
+        res = xyzz_to_affine<Q>(r);  // one inversion, on the host (needed there for Fiat-Shamir)
+    }
+    memcpy(out_xy, res.x.v, Q::N * 4);
+    memcpy(out_xy + Q::N / 2, res.y.v, Q::N * 4);
+    if (out_inf) *out_inf = aff_is_inf<Q>(res) ? 1 : 0;
+    return ZKT_OK;
+}
+
+int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf) {
+    if (c->curve == ZKT_CURVE_BN254) return msm_run_t<Bn254Curve>(c, d_scalars, n, base_off, mont, out_xy, out_inf);
+    return msm_run_t<Bls381Curve>(c, d_scalars, n, base_off, mont, out_xy, out_inf);
+}
+int msm_enqueue_only(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont) {
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    if (base_off > c->msm->count || n > c->msm->count - base_off || n == 0)
+        return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients");
+    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue<Bn254Curve>(c, d_scalars, n, base_off, mont);
+    return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont);
+}
+int srs_load(zkt_ctx* c, const void* src, size_t count, bool on_device) {
+    if (c->curve == ZKT_CURVE_BN254) return srs_load_t<Bn254Curve>(c, src, count, on_device);
+    return srs_load_t<Bls381Curve>(c, src, count, on_device);
+}
+int srs_generate(zkt_ctx* c, const uint64_t* tau4, size_t count) {
+    if (c->curve == ZKT_CURVE_BN254) return srs_generate_t<Bn254Curve>(c, tau4, count);
+    return srs_generate_t<Bls381Curve>(c, tau4, count);
+}
+int srs_download(zkt_ctx* c, size_t offset, size_t count, uint64_t* out) {
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded");
+    if (offset > c->msm->count || count > c->msm->count - offset) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "range");
+    size_t psz = (c->curve == ZKT_CURVE_BN254) ? sizeof(Affine<Bn254Fq>) : sizeof(Affine<Bls381Fq>);
+    ZKT_HIP(c, hipMemcpyAsync(out, (const char*)c->msm->table + offset * psz, count * psz, hipMemcpyDeviceToHost,
+                              c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+void msm_info(zkt_ctx* c, int* cbits, int* windows, size_t* count) {
+    if (!c->msm) {
+        *cbits = 0; *windows = 0; *count = 0;
+        return;
+    }
+    *cbits = c->msm->c;
+    *windows = c->msm->W;
+    *count = c->msm->count;
+}
+
+}  // namespace zkt
+
+using namespace zkt;
+
+extern "C" {
+
+int zkt_srs_load(zkt_ctx* c, const uint64_t* g1_xy_mont, size_t count) {
+    if (!c || !g1_xy_mont) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return srs_load(c, g1_xy_mont, count, false);
+}
+int zkt_srs_load_dev(zkt_ctx* c, const void* d_g1_xy_mont, size_t count) {
+    if (!c || !d_g1_xy_mont) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return srs_load(c, d_g1_xy_mont, count, true);
+}
+int zkt_srs_generate(zkt_ctx* c, const uint64_t* tau_canonical4, size_t count) {
+    if (!c || !tau_canonical4) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return srs_generate(c, tau_canonical4, count);
+}
+int zkt_srs_download(zkt_ctx* c, size_t offset, size_t count, uint64_t* out_xy_mont) {
+    if (!c || !out_xy_mont) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return srs_download(c, offset, count, out_xy_mont);
+}
+
+int zkt_msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t len, size_t base_offset, int scalars_montgomery,
+                   void* out_xy_mont_host) {
+    if (!c || (!d_scalars && len) || !out_xy_mont_host) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return msm_g1_dev(c, d_scalars, len, base_offset, scalars_montgomery, (uint64_t*)out_xy_mont_host, nullptr);
+}
+
+int zkt_msm_g1(zkt_ctx* c, const uint64_t* scalars, size_t len, size_t base_offset, int scalars_montgomery,
+               uint64_t* out_xy_mont, int* out_is_infinity) {
+    if (!c || (!scalars && len) || !out_xy_mont) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    if (len) {
+        int rc = ensure_buffer(c, &c->io_a, &c->io_a_bytes, len * 32);
+        if (rc) return rc;
+        ZKT_HIP(c, hipMemcpyAsync(c->io_a, scalars, len * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    return msm_g1_dev(c, c->io_a, len, base_offset, scalars_montgomery, out_xy_mont, out_is_infinity);
+}
+
+int zkt_msm_enqueue_dev(zkt_ctx* c, const void* d_scalars, size_t len, size_t base_offset, int scalars_montgomery) {
+    if (!c || !d_scalars) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    return msm_enqueue_only(c, d_scalars, len, base_offset, scalars_montgomery);
+}
+
+int zkt_msm_info(zkt_ctx* c, int* window_bits, int* windows, size_t* srs_count) {
+    if (!c || !window_bits || !windows || !srs_count) return ZKT_ERR_INVALID_ARGUMENT;
+    msm_info(c, window_bits, windows, srs_count);
+    return ZKT_OK;
+}
+
+}  // extern "C"
