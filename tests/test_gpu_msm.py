@@ -121,7 +121,7 @@ def test_msm_full_size_2_20(ctxs):
     ctx = ctxs[cv.name]
     n = 1 << 20
     ctx.srs_generate(0x5EED, n)
-    assert ctx.msm_info()["window_bits"] == 18
+    assert ctx.msm_info()["window_bits"] in (17, 18)
     srs = ctx.srs_download(0, n)
     rng = np.random.default_rng(2020)
     a = rand_fr(rng, n)

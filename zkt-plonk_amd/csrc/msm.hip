@@ -29,9 +29,23 @@ constexpr int MSM_SEG = 8;      // buckets per running-sum segment
 constexpr int MSM_R2_BLOCKS = 4;
 constexpr int MSM_MAX_Y = 24;
 
+// Window layout: W windows of width c or c-1 covering exactly lambda+1 bits, so that no window
+// (in particular not the top one) is left with only a few significant bits: a 2-bit top window
+// would pour n entries into 4 buckets.
+struct MsmWindows {
+    int W;
+    uint8_t width[40];
+    uint16_t start[40];
+};
+
+constexpr int MSM_HEAVY = 8;        // buckets with more pieces than this are folded by a whole block
+constexpr int MSM_HEAVY_BLOCKS = 512;
+
 struct MsmState {
     size_t count = 0;      // bases loaded
-    int c = 0, W = 0;      // window bits, windows
+    int c = 0, W = 0;      // max window bits, windows
+    MsmWindows win{};
+    uint32_t* heavy = nullptr;  // [0] = count, [1..] = heavy bucket ids
     uint32_t B = 0;        // buckets = 2^(c-1), ids 1..B
     void* table = nullptr; // Affine[W][count]
     // work buffers (sized for n = count)
@@ -82,7 +96,8 @@ __global__ void k_srs_generate(Affine<typename C::Fq>* out, size_t count, Fe<typ
 
 // table[w][i] = 2^(c*w) * table[0][i]
 template <class C>
-__global__ void k_srs_windows(Affine<typename C::Fq>* table, size_t count, int c, int W) {
+__global__ void k_srs_windows(Affine<typename C::Fq>* table, size_t count, MsmWindows win) {
+    const int W = win.W;
     using Q = typename C::Fq;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -95,7 +110,7 @@ __global__ void k_srs_windows(Affine<typename C::Fq>* table, size_t count, int c
 #pragma unroll 1
     for (int w = 1; w < W; ++w) {
 #pragma unroll 1
-        for (int k = 0; k < c; ++k) acc = xyzz_double<Q>(acc);
+        for (int k = 0; k < (int)win.width[w - 1]; ++k) acc = xyzz_double<Q>(acc);
         Affine<Q> a = xyzz_to_affine<Q>(acc);
         aff_store<Q>(table + (size_t)w * count + i, a);
         acc = xyzz_from_affine<Q>(a);
@@ -106,18 +121,19 @@ __global__ void k_srs_windows(Affine<typename C::Fq>* table, size_t count, int c
 // digits
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mont, int c, int W, size_t count,
+__global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mont, MsmWindows win, size_t count,
                              size_t base_off, uint32_t* keys, uint32_t* vals) {
+    const int W = win.W;
     using R = typename C::Fr;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<R> s = fe_load<R>(scalars + i);
     if (mont) s = fe_from_mont<R>(s);
-    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
     uint64_t buf = 0;
     int bits = 0, w = 0;
     uint32_t carry = 0;
-    auto emit = [&](uint32_t raw) {
+    auto emit = [&](uint32_t raw, int c) {
+        const uint32_t half = 1u << (c - 1);
         uint32_t d = raw + carry, neg = 0;
         if (d > half) {
             d = (1u << c) - d;
@@ -134,14 +150,16 @@ __global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mo
     for (int li = 0; li < R::N; ++li) {
         buf |= (uint64_t)s.v[li] << bits;
         bits += 32;
-        while (bits >= c && w < W) {
-            emit((uint32_t)buf & mask);
+        while (w < W && bits >= (int)win.width[w]) {
+            const int c = win.width[w];
+            emit((uint32_t)buf & ((1u << c) - 1u), c);
             buf >>= c;
             bits -= c;
         }
     }
     while (w < W) {
-        emit((uint32_t)buf & mask);
+        const int c = win.width[w];
+        emit((uint32_t)buf & ((1u << c) - 1u), c);
         buf >>= c;
     }
 }
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, co
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B,
                                                         const Xyzz<typename C::Fq>* pieces,
-                                                        Xyzz<typename C::Fq>* buckets) {
+                                                        Xyzz<typename C::Fq>* buckets, uint32_t* heavy) {
     using Q = typename C::Fq;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..B ; bucket 0 is the identity
     if (b > B) return;
@@ -211,11 +229,66 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets,
         const uint32_t s = offsets[b], e = offsets[b + 1];
         if (e > s) {
             const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+            if (t1 - t0 >= MSM_HEAVY) {  // crowded bucket: leave it to k_msm_heavy
+                heavy[1 + atomicAdd(heavy, 1u)] = b;
+                return;
+            }
             acc = xyzz_load<Q>(pieces + (size_t)t0 + b);
             for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xyzz_add<Q>(acc, xyzz_load<Q>(pieces + (size_t)t + b));
         }
     }
     xyzz_store<Q>(buckets + b, acc);
+}
+
+template <class Q>
+ZKT_D Xyzz<Q> xyzz_shfl_down(const Xyzz<Q>& p, int delta) {
+    Xyzz<Q> r;
+#pragma unroll
+    for (int i = 0; i < Q::N; ++i) {
+        r.x.v[i] = __shfl_down(p.x.v[i], delta);
+        r.y.v[i] = __shfl_down(p.y.v[i], delta);
+        r.zz.v[i] = __shfl_down(p.zz.v[i], delta);
+        r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta);
+    }
+    return r;
+}
+
+// block-wide sum of one XYZZ value per thread (256 threads); result valid in thread 0
+template <class Q>
+ZKT_D Xyzz<Q> block_sum_256(Xyzz<Q> acc, Xyzz<Q>* wsum /* 4 entries of LDS */) {
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<Q> o = xyzz_shfl_down<Q>(acc, d);
+        acc = xyzz_add<Q>(acc, o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc = wsum[0];
+        for (int i = 1; i < 4; ++i) acc = xyzz_add<Q>(acc, wsum[i]);
+    }
+    __syncthreads();
+    return acc;
+}
+
+// crowded buckets (skewed digit distributions): one block folds all pieces of one bucket
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, const Xyzz<typename C::Fq>* pieces,
+                                                   Xyzz<typename C::Fq>* buckets, const uint32_t* heavy) {
+    using Q = typename C::Fq;
+    __shared__ Xyzz<Q> wsum[4];
+    const uint32_t nheavy = heavy[0];
+    const uint32_t base = offsets[1];
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t b = heavy[1 + h];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+        Xyzz<Q> acc = xyzz_identity<Q>();
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xyzz_add<Q>(acc, xyzz_load<Q>(pieces + (size_t)t + b));
+        acc = block_sum_256<Q>(acc, wsum);
+        if (threadIdx.x == 0) xyzz_store<Q>(buckets + b, acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,19 +313,6 @@ __global__ __launch_bounds__(256) void k_msm_segments(const Xyzz<typename C::Fq>
     xyzz_store<Q>(segT + s, run);
 }
 
-template <class Q>
-ZKT_D Xyzz<Q> xyzz_shfl_down(const Xyzz<Q>& p, int delta) {
-    Xyzz<Q> r;
-#pragma unroll
-    for (int i = 0; i < Q::N; ++i) {
-        r.x.v[i] = __shfl_down(p.x.v[i], delta);
-        r.y.v[i] = __shfl_down(p.y.v[i], delta);
-        r.zz.v[i] = __shfl_down(p.zz.v[i], delta);
-        r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta);
-    }
-    return r;
-}
-
 // y = 0: plain sum of segA ; y = k + 1: sum of segT[s] over s with bit k set.  One partial per block.
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::Fq>* segA,
@@ -266,19 +326,8 @@ __global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
         if (y == 0 || ((s >> (y - 1)) & 1u)) acc = xyzz_add<Q>(acc, xyzz_load<Q>(src + s));
     }
-#pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
-        Xyzz<Q> o = xyzz_shfl_down<Q>(acc, d);
-        acc = xyzz_add<Q>(acc, o);
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wsum[wv] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Xyzz<Q> t = wsum[0];
-        for (int i = 1; i < 4; ++i) t = xyzz_add<Q>(t, wsum[i]);
-        xyzz_store<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, t);
-    }
+    acc = block_sum_256<Q>(acc, wsum);
+    if (threadIdx.x == 0) xyzz_store<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
 }
 
 // result = sum_y 2^(e_y) * V_y ; V_y = sum of the y-th row of partials, plus the top bucket with e = c-1
@@ -326,8 +375,21 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     int cb = lg - 2;
     if (cb < 8) cb = 8;
     if (cb > 18) cb = 18;
-    st->c = cb;
-    st->W = (R::BITS + 1 + cb - 1) / cb;
+    {   // W windows of width cmax or cmax-1 covering exactly lambda+1 bits
+        const int total = R::BITS + 1;
+        const int W = (total + cb - 1) / cb;
+        const int lo = total / W, rem = total % W;
+        st->win.W = W;
+        int pos = 0;
+        for (int w = 0; w < W; ++w) {
+            st->win.width[w] = (uint8_t)(lo + (w < rem ? 1 : 0));
+            st->win.start[w] = (uint16_t)pos;
+            pos += st->win.width[w];
+        }
+        st->W = W;
+        st->c = lo + (rem ? 1 : 0);
+        cb = st->c;
+    }
     st->B = 1u << (cb - 1);
     if ((uint64_t)st->W * count >= ((uint64_t)1 << 31))
         return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "SRS too large for 31-bit table indices");
@@ -343,6 +405,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
                                        st->c, c->stream);
     if ((rc = dev_alloc(c, &st->cub_tmp, st->cub_bytes + 256))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->B + 2) * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
     size_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
     if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(Xyzz<Q>)))) return rc;
     if ((rc = dev_alloc(c, &st->buckets, ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
@@ -361,8 +424,7 @@ static int srs_finish(zkt_ctx* c) {
     using Q = typename C::Fq;
     MsmState& st = *c->msm;
     unsigned blocks = (unsigned)((st.count + 127) / 128);
-    hipLaunchKernelGGL(k_srs_windows<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)st.table, st.count, st.c,
-                       st.W);
+    hipLaunchKernelGGL(k_srs_windows<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)st.table, st.count, st.win);
     ZKT_HIP(c, hipGetLastError());
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
     return ZKT_OK;
@@ -372,7 +434,7 @@ static void msm_release(zkt_ctx* c) {
     if (!c->msm) return;
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {st.table, st.keys, st.keys2, st.vals, st.vals2, st.cub_tmp, st.offsets, st.pieces,
+    void* ptrs[] = {st.heavy, st.table, st.keys, st.keys2, st.vals, st.vals2, st.cub_tmp, st.offsets, st.pieces,
                     st.buckets, st.segA, st.segT, st.partials, st.result};
     for (void* p : ptrs) dev_free(c, p);
     c->msm.reset();
@@ -444,7 +506,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     {
         unsigned blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_msm_digits<C>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<R>*)d_scalars, n, mont,
-                           st.c, st.W, st.count, base_off, st.keys, st.vals);
+                           st.win, st.count, base_off, st.keys, st.vals);
         ZKT_HIP(c, hipGetLastError());
     }
     size_t tmp = st.cub_bytes;
@@ -459,8 +521,12 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
                            st.vals2, m, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
+    ZKT_HIP(c, hipMemsetAsync(st.heavy, 0, 4, c->stream));
     hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
-                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets);
+                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets, st.heavy);
+    ZKT_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, c->stream, st.offsets,
+                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets, st.heavy);
     ZKT_HIP(c, hipGetLastError());
     const uint32_t nseg = st.B / MSM_SEG;
     hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, c->stream,
