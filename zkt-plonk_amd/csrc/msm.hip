@@ -24,7 +24,7 @@
 
 namespace zkt {
 
-constexpr int MSM_CHUNK = 32;   // sorted entries per accumulation thread
+constexpr int MSM_CHUNK = 64;   // sorted entries per accumulation thread
 constexpr int MSM_SEG = 8;      // buckets per running-sum segment
 constexpr int MSM_R2_BLOCKS = 4;
 constexpr int MSM_MAX_Y = 24;
@@ -38,7 +38,7 @@ struct MsmWindows {
     uint16_t start[40];
 };
 
-constexpr int MSM_HEAVY = 8;        // buckets with more pieces than this are folded by a whole block
+constexpr int MSM_HEAVY = 32;       // buckets with more pieces than this are folded by a whole block
 constexpr int MSM_HEAVY_BLOCKS = 512;
 
 struct MsmState {
