@@ -112,6 +112,71 @@ int zkt_msm_enqueue_dev(zkt_ctx* ctx, const void* d_scalars, size_t len, size_t 
 /* Window size c, number of windows and loaded powers of the current SRS (0s when none). */
 int zkt_msm_info(zkt_ctx* ctx, int* window_bits, int* windows, size_t* srs_count);
 
+/* ---- Fiat-Shamir transcripts (host side; T: TranscriptProtocol, plonk-core/src/transcript.rs:16-45) */
+enum {
+    ZKT_TRANSCRIPT_MERLIN = 0,   /* MerlinTranscript, plonk-core/src/transcript.rs:46-109 (merlin 3.0) */
+    ZKT_TRANSCRIPT_ETHEREUM = 1  /* EthereumTranscript, gadgets/src/transcript.rs:8-90 (BN254 only)   */
+};
+typedef struct zkt_transcript zkt_transcript;
+/* T::new(label) (plonk.rs:105).  Scalars/coordinates are canonical little-endian bytes here. */
+zkt_transcript* zkt_transcript_new(int kind, const char* label);
+void zkt_transcript_free(zkt_transcript* t);
+void zkt_transcript_append_u64(zkt_transcript* t, const char* label, uint64_t v);            /* transcript.rs:58-60 */
+/* count scalars of 32 bytes; single != 0 mirrors append_scalar, 0 mirrors append_scalars (transcript.rs:62-79) */
+void zkt_transcript_append_scalars(zkt_transcript* t, const char* label, const uint8_t* le32, size_t count, int single);
+void zkt_transcript_append_commitment(zkt_transcript* t, const char* label, const uint8_t* x_le, const uint8_t* y_le,
+                                      size_t fq_bytes, int is_infinity);                      /* transcript.rs:81-86 */
+void zkt_transcript_challenge_scalar(zkt_transcript* t, const char* label, int fr_bits, uint8_t out_le32[32]); /* :101-108 */
+/* raw merlin access (conformance vectors); ZKT_ERR_INVALID_ARGUMENT on a non-merlin transcript */
+int zkt_transcript_append_message(zkt_transcript* t, const char* label, const uint8_t* msg, size_t len);
+int zkt_transcript_challenge_bytes(zkt_transcript* t, const char* label, uint8_t* out, size_t len);
+
+/* Foreign transcript: the Rust shim implements these four callbacks on top of its own
+ * `T: TranscriptProtocol<F, PC::Commitment>`; values cross as arkworks Montgomery limbs. */
+typedef struct {
+    void* user;
+    void (*append_u64)(void* user, const char* label, uint64_t v);
+    void (*append_scalars)(void* user, const char* label, const uint64_t* fr_mont, size_t count, int single);
+    void (*append_commitment)(void* user, const char* label, const uint64_t* g1_xy_mont, int is_infinity);
+    void (*challenge_scalar)(void* user, const char* label, uint64_t* fr_mont_out4);
+} zkt_transcript_vtable;
+
+/* ---- Prover: proof_system::prove (plonk-core/src/proof_system/prove.rs:59-470) ---------------- */
+/* Loads the preprocessed circuit: the ten ProverKey polynomials in coefficient form
+ * (keys/mod.rs:29-77), order q_m, q_l, q_r, q_o, q_c, sigma1, sigma2, sigma3, q_lookup, q_table, each
+ * pk_lens[k] <= n = 2^log_n coefficients (trailing zeros stripped or not).  The ExtendedProverKey
+ * (keys/mod.rs:78-174: 13 coset vectors on the 4n domain, sigma / q_lookup evaluations) is derived on
+ * the device and stays resident in HBM; it never crosses PCIe. */
+int zkt_circuit_load(zkt_ctx* ctx, int log_n, const uint64_t* const* pk_polys, const size_t* pk_lens);
+
+typedef struct {
+    /* wire_evals() of the proving composer (prove.rs:49-55,116): n_rows <= n values each, zero padded */
+    const uint64_t* a_evals;
+    const uint64_t* b_evals;
+    const uint64_t* c_evals;
+    size_t n_rows;
+    /* the lookup table as a LookupTable IndexSet (lookup/table.rs:19): distinct values, insertion order */
+    const uint64_t* table;
+    size_t table_len;
+    /* PublicInputs BTreeMap (constraint_system/pi.rs:52-105): ascending positions and their values */
+    const size_t* pi_pos;
+    const uint64_t* pi_vals;
+    size_t n_pi;
+    /* the 19 F::rand(rng) draws of prove.rs in reference order:
+     * a(2) b(2) c(2) h1(3) h2(2) z1(3) z2(3) b0 b1   (prove.rs:125-127,170-171,225,244,296) */
+    const uint64_t* blinders;
+} zkt_prove_inputs;
+
+/* Runs the five prover rounds on the device and writes the CanonicalSerialize bytes of
+ * Proof<F, D, KZG10<E>> (proof.rs:106-155): 802 bytes on BN254, 1010 on BLS12-381.  The transcript must
+ * already be seeded by VerifierKey::seed_transcript (keys/mod.rs:260-275), as in plonk.rs:105-108.
+ * Needs zkt_srs_load (>= n + 8 powers) and zkt_circuit_load.  Errors mirror the reference's Err / panics:
+ * ZKT_ERR_NOT_IN_TABLE, ZKT_ERR_EQUAL_CHALLENGES, ZKT_ERR_ZERO_DENOMINATOR, ZKT_ERR_QUOTIENT_TOO_SHORT. */
+int zkt_prove(zkt_ctx* ctx, const zkt_prove_inputs* in, zkt_transcript* transcript, uint8_t* proof_out,
+              size_t proof_cap, size_t* proof_len);
+int zkt_prove_with(zkt_ctx* ctx, const zkt_prove_inputs* in, const zkt_transcript_vtable* transcript,
+                   uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+
 /* ---- debug / test support ------------------------------------------------------------------ */
 /* Dumps the compiled-in parameter tables (modulus, -p^-1 mod 2^32, R, R^2) as u32 words for
  * which = 0 (Fr) or 1 (Fq) of the context's curve; returns the limb count. */

@@ -1,0 +1,123 @@
+"""GPU parity of the full prover (proof bytes) against the CPU oracle and the committed golden proof."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fields as F, curve as C, plonk as P, coracle as K
+from helpers import field_elems, unhex_point
+
+CURVES = [F.BN254, F.BLS12_381]
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import zkt_plonk_amd as z
+    c = {cv.name: z.Context(cv.name, 0) for cv in CURVES}
+    yield c
+    for x in c.values():
+        x.close()
+
+
+def _gpu_prove(z, ctx, cv, cs, pk, vk, srs_arr, blinders, kind="merlin"):
+    n = cs.circuit_bound()
+    log_n = n.bit_length() - 1
+    ctx.srs_load(srs_arr[:n + 8])
+    prover = z.GpuProver(ctx, log_n, {k: K.fr_to_mont(cv, pk.polys[k]) if pk.polys[k] else np.zeros((0, 4), dtype=np.uint64)
+                                      for k in z.PK_ORDER})
+    tr = z.Transcript(kind, "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+    z.seed_transcript(tr, vk.n, vk.commits)
+    a, b, c = cs.wire_evals(cs.n_gates)
+    pi = {pos: K.fr_to_mont(cv, [v])[0] for pos, v in cs.pi.items()}
+    return prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c),
+                        K.fr_to_mont(cv, cs.table) if cs.table else np.zeros((0, 4), dtype=np.uint64),
+                        pi, K.fr_to_mont(cv, blinders), tr)
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_reference_test_circuit_golden_proof_bytes(cv, ctxs, golden):
+    """plonk-core/src/plonk.rs:144-218 TestCircuit, n = 128: the GPU proof equals the committed bytes."""
+    import zkt_plonk_amd as z
+    g = golden[cv.name]["test_circuit"]
+    tau = int(golden[cv.name]["tau"], 16)
+    cs = P.test_circuit(cv)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    assert {k: unhex_point(v) for k, v in g["vk"].items()} == vk.commits
+    blinders = field_elems(cv.fr.p, g["blinder_seed"], P.NUM_BLINDERS)
+    proof = _gpu_prove(z, ctxs[cv.name], cv, cs, pk, vk, srs_arr, blinders)
+    assert len(proof) == (802 if cv.name == "bn254" else 1010)
+    assert proof.hex() == g["proof_bytes"]
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("gates,table_size", [(60, 16), (1000, 64), (4000, 1024)])
+def test_synthetic_circuits_match_oracle(cv, gates, table_size, ctxs):
+    import zkt_plonk_amd as z
+    cs = P.synthetic_circuit(cv, gates, table_size, seed=gates)
+    assert cs.check_satisfied()
+    n = cs.circuit_bound()
+    tau = 0xABCDEF0123456789 + gates
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(cv.fr.p, 77 + gates, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders)
+    got = _gpu_prove(z, ctxs[cv.name], cv, cs, pk, vk, srs_arr, blinders)
+    assert got == want.serialize(cv)
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    assert P.verify(cv, tau, vk, want, P.new_seeded_transcript(cv, vk), pis)
+
+
+def test_ethereum_transcript_proof_matches_oracle(ctxs):
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    cs = P.synthetic_circuit(cv, 200, 32, seed=5)
+    n = cs.circuit_bound()
+    tau = 424242
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(cv.fr.p, 9, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk, "ethereum"), blinders)
+    got = _gpu_prove(z, ctxs[cv.name], cv, cs, pk, vk, srs_arr, blinders, kind="ethereum")
+    assert got == want.serialize(cv)
+
+
+def test_prover_error_paths(ctxs):
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 100, 16, seed=8)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, 777, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(cv.fr.p, 1, P.NUM_BLINDERS)
+    # a looked-up value that is not in the table -> Error::ElementNotIndexedInTable (multiset.rs:121)
+    row = next(i for i, q in enumerate(cs.q_lookup) if q)
+    bad = P.ConstraintSystem.__new__(P.ConstraintSystem)
+    bad.__dict__.update(cs.__dict__)
+    bad.values = list(cs.values)
+    bad.values[cs.w_o[row]] = (cs.values[cs.w_o[row]] + 1) % cv.fr.p
+    with pytest.raises(z.ZktError) as e:
+        _gpu_prove(z, ctx, cv, bad, pk, vk, srs_arr, blinders)
+    assert e.value.code == 8
+    # an unsatisfied arithmetic gate -> the quotient is not a polynomial of degree 3n+5
+    row = next(i for i, q in enumerate(cs.q_lookup) if not q and cs.w_o[i] >= 0 and cs.q_o[i])
+    bad.values = list(cs.values)
+    bad.values[cs.w_o[row]] = (cs.values[cs.w_o[row]] + 1) % cv.fr.p
+    with pytest.raises(z.ZktError) as e:
+        _gpu_prove(z, ctx, cv, bad, pk, vk, srs_arr, blinders)
+    assert e.value.code in (8, 9)
+    # SRS too short for the circuit -> kzg10 TooManyCoefficients
+    ctx.srs_load(srs_arr[:n // 2])
+    prover = z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+    tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)
+    a, b, c = cs.wire_evals(cs.n_gates)
+    with pytest.raises(z.ZktError) as e:
+        prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
+                     {p_: K.fr_to_mont(cv, [v])[0] for p_, v in cs.pi.items()}, K.fr_to_mont(cv, blinders), tr)
+    assert e.value.code == 5

@@ -10,8 +10,9 @@ All numerics run in ``libzkt_plonk_hip.so`` (hand-written HIP kernels).  There i
 importing works without a GPU (so the C-ABI can be inspected), creating a ``Context`` does not.
 """
 from ._lib import (  # noqa: F401
-    Context, ZktError, lib, lib_path, CURVE_BN254, CURVE_BLS12_381, curve_id, declared_symbols,
+    Context, ZktError, Transcript, lib, lib_path, CURVE_BN254, CURVE_BLS12_381, curve_id, declared_symbols,
 )
 from .domain import GpuDomain  # noqa: F401
+from .prover import GpuProver, seed_transcript, PK_ORDER, NUM_BLINDERS  # noqa: F401
 
 __all__ = ["Context", "ZktError", "GpuDomain", "lib", "lib_path", "CURVE_BN254", "CURVE_BLS12_381"]

@@ -68,6 +68,7 @@ def lib():
         L.zkt_debug_params.argtypes = [vp, ctypes.c_int, u32p, ctypes.c_size_t]
         L.zkt_debug_fr_mul.argtypes = [vp, u64p, u64p, ctypes.c_size_t, u64p]
         _bind_optional(L)
+        _bind_prover(L)
         _lib = L
     return _lib
 
@@ -84,6 +85,87 @@ def _bind_optional(L):
         L.zkt_msm_g1_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp]
         L.zkt_msm_enqueue_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
         L.zkt_msm_info.argtypes = [vp, ip, ip, ctypes.POINTER(ctypes.c_size_t)]
+
+
+class ProveInputs(ctypes.Structure):
+    _fields_ = [("a_evals", ctypes.POINTER(ctypes.c_uint64)), ("b_evals", ctypes.POINTER(ctypes.c_uint64)),
+                ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),
+                ("table", ctypes.POINTER(ctypes.c_uint64)), ("table_len", ctypes.c_size_t),
+                ("pi_pos", ctypes.POINTER(ctypes.c_size_t)), ("pi_vals", ctypes.POINTER(ctypes.c_uint64)),
+                ("n_pi", ctypes.c_size_t), ("blinders", ctypes.POINTER(ctypes.c_uint64))]
+
+
+def _bind_prover(L):
+    vp, u64p_, u8p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint8)
+    L.zkt_transcript_new.restype = vp
+    L.zkt_transcript_new.argtypes = [ctypes.c_int, ctypes.c_char_p]
+    L.zkt_transcript_free.argtypes = [vp]
+    L.zkt_transcript_free.restype = None
+    L.zkt_transcript_append_u64.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64]
+    L.zkt_transcript_append_u64.restype = None
+    L.zkt_transcript_append_scalars.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    L.zkt_transcript_append_scalars.restype = None
+    L.zkt_transcript_append_commitment.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                                   ctypes.c_size_t, ctypes.c_int]
+    L.zkt_transcript_append_commitment.restype = None
+    L.zkt_transcript_challenge_scalar.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, u8p]
+    L.zkt_transcript_challenge_scalar.restype = None
+    L.zkt_transcript_append_message.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.zkt_transcript_challenge_bytes.argtypes = [vp, ctypes.c_char_p, u8p, ctypes.c_size_t]
+    L.zkt_circuit_load.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64p_), ctypes.POINTER(ctypes.c_size_t)]
+    L.zkt_prove.argtypes = [vp, ctypes.POINTER(ProveInputs), vp, u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+
+
+class Transcript:
+    """Built-in host transcript (T: TranscriptProtocol): kind 'merlin' (plonk-core/src/transcript.rs:46-109)
+    or 'ethereum' (gadgets/src/transcript.rs:8-90).  Scalars / coordinates are canonical integers."""
+
+    def __init__(self, kind: str = "merlin", label: str = "ZKT Plonk", fr_bits: int = 254, fq_bytes: int = 32):
+        self._L = lib()
+        self._h = ctypes.c_void_p(self._L.zkt_transcript_new(0 if kind == "merlin" else 1, label.encode()))
+        self.fr_bits = fr_bits
+        self.fq_bytes = fq_bytes
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.zkt_transcript_free(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def append_u64(self, label: str, v: int):
+        self._L.zkt_transcript_append_u64(self._h, label.encode(), v)
+
+    def append_scalar(self, label: str, v: int):
+        self._L.zkt_transcript_append_scalars(self._h, label.encode(), int(v).to_bytes(32, "little"), 1, 1)
+
+    def append_scalars(self, label: str, vals):
+        vals = list(vals)
+        self._L.zkt_transcript_append_scalars(self._h, label.encode(),
+                                              b"".join(int(v).to_bytes(32, "little") for v in vals), len(vals), 0)
+
+    def append_commitment(self, label: str, point):
+        nb = self.fq_bytes
+        if point is None:
+            self._L.zkt_transcript_append_commitment(self._h, label.encode(), bytes(nb), bytes(nb), nb, 1)
+        else:
+            self._L.zkt_transcript_append_commitment(self._h, label.encode(), int(point[0]).to_bytes(nb, "little"),
+                                                     int(point[1]).to_bytes(nb, "little"), nb, 0)
+
+    def challenge_scalar(self, label: str) -> int:
+        out = (ctypes.c_uint8 * 32)()
+        self._L.zkt_transcript_challenge_scalar(self._h, label.encode(), self.fr_bits, out)
+        return int.from_bytes(bytes(out), "little")
+
+    def append_message(self, label: bytes, msg: bytes):
+        assert self._L.zkt_transcript_append_message(self._h, label, msg, len(msg)) == 0
+
+    def challenge_bytes(self, label: bytes, n: int) -> bytes:
+        out = (ctypes.c_uint8 * n)()
+        assert self._L.zkt_transcript_challenge_bytes(self._h, label, out, n) == 0
+        return bytes(out)
 
 
 def u64p(a: np.ndarray):
@@ -199,6 +281,31 @@ class Context:
         c, w, n = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_size_t(0)
         self.check(self._L.zkt_msm_info(self._h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(n)))
         return dict(window_bits=c.value, windows=w.value, srs_count=n.value)
+
+    # -- prover -----------------------------------------------------------------------------------------
+    def circuit_load(self, log_n: int, pk_polys):
+        """pk_polys: 10 arrays (len_k, 4) in the order q_m q_l q_r q_o q_c sigma1 sigma2 sigma3 q_lookup q_table."""
+        arrs = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in pk_polys]
+        assert len(arrs) == 10
+        ptrs = (ctypes.POINTER(ctypes.c_uint64) * 10)(*[u64p(a) if a.size else ctypes.POINTER(ctypes.c_uint64)() for a in arrs])
+        lens = (ctypes.c_size_t * 10)(*[a.shape[0] for a in arrs])
+        self.check(self._L.zkt_circuit_load(self._h, log_n, ptrs, lens))
+
+    def prove(self, a, b, c, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
+        """proof_system::prove (prove.rs:59-470); all arrays are (len, 4) Montgomery uint64."""
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c))
+        table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+        pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
+        blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
+        pos = (ctypes.c_size_t * max(1, len(pi_pos)))(*pi_pos)
+        null = ctypes.POINTER(ctypes.c_uint64)()
+        inp = ProveInputs(u64p(a) if a.size else null, u64p(b) if b.size else null, u64p(c) if c.size else null,
+                          a.shape[0], u64p(table) if table.size else null, table.shape[0], pos,
+                          u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders))
+        out = (ctypes.c_uint8 * 2048)()
+        n = ctypes.c_size_t(0)
+        self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))
+        return bytes(out[:n.value])
 
     # -- debug hooks ----------------------------------------------------------------------------------
     def debug_params(self, which: int):

@@ -1,0 +1,68 @@
+// Device-side polynomial / evaluation-vector kernels of the prover rounds (launch wrappers).
+// Each wrapper cites the reference code it replaces; implementations are in poly.hip.
+#pragma once
+#include "ctx.hpp"
+
+namespace zkt {
+
+constexpr int LC_MAX_TERMS = 16;
+struct LinCombArgs {            // out[i] = sum_k scalar[k] * poly[k][i]  (poly k read as zero beyond len[k])
+    const void* poly[LC_MAX_TERMS];
+    uint64_t len[LC_MAX_TERMS];
+    uint32_t scalar[LC_MAX_TERMS][8];  // Montgomery
+    int nterms;
+};
+
+constexpr int EVAL_MAX = 16;
+struct EvalArgs {               // result[k] = poly[k](point[k])
+    const void* poly[EVAL_MAX];
+    uint64_t len[EVAL_MAX];
+    uint32_t point[EVAL_MAX][8];
+    int count;
+};
+
+struct QuotientArgs {           // all vectors hold 4n coset evaluations
+    const void *a, *b, *c, *pi, *z1, *z2, *t, *h1, *h2;
+    const void *q_m, *q_l, *q_r, *q_o, *q_c, *q_lookup, *q_table, *sigma1, *sigma2, *sigma3, *x, *l1;
+    void* out;
+    uint32_t alpha[8], beta[8], gamma[8], delta[8], epsilon[8];
+    uint32_t zh_inv[4][8];      // 1 / (x^n - 1) on the coset: depends on i mod 4 only
+    uint64_t n4;
+};
+
+struct ZTermsArgs {
+    const void *a, *b, *c, *s1, *s2, *s3, *roots;  // z1
+    const void *f, *t, *h1, *h2;                    // z2
+    void *num, *den;
+    uint32_t beta[8], gamma[8], delta[8], epsilon[8];
+    uint64_t n;
+};
+
+// elementwise
+int poly_mul_vec(zkt_ctx* c, const void* a, const void* b, void* out, size_t n);              // prove.rs:157-161
+int poly_set_zero(zkt_ctx* c, void* p, size_t n_elems);
+int poly_trim_len(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len);                       // from_coefficients_vec
+int poly_add_blinders(zkt_ctx* c, void* p, const uint32_t* d_len, const void* d_blinders, int k, size_t cap);  // prove.rs:472-483
+int poly_lincomb(zkt_ctx* c, const LinCombArgs& a, void* out, size_t n);
+int poly_eval_many(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results);         // linearization_poly.rs:55-75
+// grand products (permutation/mod.rs:181-254, lookup/mod.rs:94-151)
+int z1_terms(zkt_ctx* c, const ZTermsArgs& a);
+int z2_terms(zkt_ctx* c, const ZTermsArgs& a);
+int scan_mul(zkt_ctx* c, const void* in, void* out, size_t n, bool reverse, void* d_tmp /* >= 2*(n/1024 + 2048) elems */);
+int scan_add(zkt_ctx* c, const void* in, void* out, size_t n, bool reverse, void* d_tmp);
+int z_combine(zkt_ctx* c, const void* pn, const void* sd, const uint32_t inv_total[8], void* out, size_t n);
+// quotient (quotient_poly.rs:98-224)
+int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a);
+int quotient_split_blind(zkt_ctx* c, const void* q, size_t n, const void* d_b0b1, void* q_lo, void* q_mid, void* q_hi,
+                         uint32_t* d_status);                                                   // prove.rs:287-300
+// KZG opening witness: w = p / (X - z)  (kzg10::compute_witness_polynomial)
+int open_witness(zkt_ctx* c, const void* p, size_t len, const uint32_t z[8], const uint32_t z_inv[8], void* d_tmp_a,
+                 void* d_tmp_b, void* d_scan_tmp, void* out);
+// table generation
+int gen_powers(zkt_ctx* c, void* out, size_t n, const uint32_t base[8], const uint32_t scale[8]);
+// Plookup sorted halves h1/h2 (lookup/multiset.rs:103-146)
+int lookup_count(zkt_ctx* c, const void* f, size_t n, const void* d_sorted_keys, const uint32_t* d_perm, uint32_t nkeys,
+                 uint32_t* d_counts, uint32_t* d_status);
+int lookup_expand(zkt_ctx* c, const void* d_keys_insertion, const uint32_t* d_starts, uint32_t nkeys, void* out, size_t n);
+
+}  // namespace zkt

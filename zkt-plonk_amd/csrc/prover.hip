@@ -1,0 +1,744 @@
+// Device-resident PLONK+Plookup prover: host orchestration of the five rounds of
+// plonk-core/src/proof_system/prove.rs:59-470.  Witness vectors are uploaded once; every
+// polynomial stays in HBM between rounds; only commitments (affine points), the 12 evaluations and
+// two scalars (the grand-product denominators) cross PCIe, for the host-side Fiat-Shamir transcript.
+#include "ctx.hpp"
+#include "ec.hpp"
+#include "poly.hpp"
+#include "transcript.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+namespace zkt {
+
+// msm.hip
+int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf);
+
+enum { PK_QM = 0, PK_QL, PK_QR, PK_QO, PK_QC, PK_S1, PK_S2, PK_S3, PK_QLOOKUP, PK_QTABLE, PK_COUNT };
+// coset vectors kept on the device (keys/mod.rs:153-174; x and l_1 are stored, zh is 4 scalars)
+enum { CS_QM = 0, CS_QL, CS_QR, CS_QO, CS_QC, CS_QLOOKUP, CS_QTABLE, CS_S1, CS_S2, CS_S3, CS_X, CS_L1, CS_COUNT };
+enum { W_A = 0, W_B, W_C, W_PI, W_Z1, W_Z2, W_T, W_H1, W_H2, W_COUNT };  // witness cosets of quotient_poly.rs:52-96
+
+struct CircuitState {
+    int log_n = 0;
+    size_t n = 0;
+    void* pk[PK_COUNT] = {};
+    size_t pk_len[PK_COUNT] = {};
+    void* coset[CS_COUNT] = {};
+    void* sigma_ev[3] = {};
+    void* q_lookup_ev = nullptr;
+    void* roots = nullptr;
+    uint32_t zh_inv[4][8] = {};
+    // per-proof work buffers
+    void* ev[8] = {};       // a, b, c, t, f, h1, h2, pi   (n each)
+    void* sc[4] = {};       // scan scratch: num, den, PN, SD (n each)
+    void* scan_tmp = nullptr;
+    void* poly[13] = {};    // a b c t h1 h2 z1 z2 pi q_lo q_mid q_hi work   (n + 8 each)
+    void* wcos[W_COUNT] = {};
+    void* qev = nullptr;    // 4n
+    void* small = nullptr;  // blinders (19), eval partials, eval results
+    uint32_t* status = nullptr;  // [0] error bits, [1] len scratch ... [4..7] quotient lens, [8..] poly lens
+    uint32_t* lk_u32 = nullptr;  // lookup: perm, counts, starts
+    void* lk_keys = nullptr;     // insertion-order keys then sorted keys
+    size_t lk_cap = 0;
+    void* pinned = nullptr;
+};
+
+// ---- host field helpers ------------------------------------------------------------------------------
+template <class P>
+struct HostF {
+    using F = Fe<P>;
+    static F from_words(const uint64_t* w) {
+        F r;
+        memcpy(r.v, w, 32);
+        return r;
+    }
+    static void to_le_bytes(const F& mont, uint8_t out[32]) {
+        F c = fe_from_mont<P>(mont);
+        memcpy(out, c.v, 32);
+    }
+    static F from_le_bytes(const uint8_t in[32]) {
+        F c;
+        memcpy(c.v, in, 32);
+        return fe_to_mont<P>(c);
+    }
+    static F pow_u64(F a, uint64_t e) { return fe_pow_u64<P>(a, e); }
+};
+
+template <class Q>
+static void fq_to_le(const Fe<Q>& mont, uint8_t* out) {
+    Fe<Q> c = fe_from_mont<Q>(mont);
+    memcpy(out, c.v, Q::N * 4);
+}
+
+// ark-serialize 0.3 compressed short-Weierstrass point (proof wire format, proof.rs:98-155):
+// x little-endian, bit 7 of the last byte = y > -y, bit 6 = infinity.
+template <class Q>
+static void serialize_point(const Affine<Q>& p, std::vector<uint8_t>& out) {
+    const size_t nb = Q::N * 4;
+    std::vector<uint8_t> b(nb, 0);
+    if (aff_is_inf<Q>(p)) {
+        b[nb - 1] |= 0x40;
+    } else {
+        fq_to_le<Q>(p.x, b.data());
+        Fe<Q> y = fe_from_mont<Q>(p.y);
+        Fe<Q> ny = fe_from_mont<Q>(fe_neg<Q>(p.y));
+        bool greater = false;
+        for (int i = Q::N - 1; i >= 0; --i) {
+            if (y.v[i] != ny.v[i]) {
+                greater = y.v[i] > ny.v[i];
+                break;
+            }
+        }
+        if (greater) b[nb - 1] |= 0x80;
+    }
+    out.insert(out.end(), b.begin(), b.end());
+}
+
+template <class C>
+struct Prover {
+    using R = typename C::Fr;
+    using Q = typename C::Fq;
+    using F = Fe<R>;
+    using H = HostF<R>;
+
+    zkt_ctx* c;
+    CircuitState& S;
+    HostTranscript& tr;
+    Prover(zkt_ctx* ctx, CircuitState& st, HostTranscript& t) : c(ctx), S(st), tr(t) {}
+
+    void tr_commit(const char* label, const Affine<Q>& p) {
+        uint8_t x[64], y[64];
+        bool inf = aff_is_inf<Q>(p);
+        if (!inf) {
+            fq_to_le<Q>(p.x, x);
+            fq_to_le<Q>(p.y, y);
+        }
+        tr.append_commitment(label, x, y, Q::N * 4, inf);
+    }
+    void tr_scalar(const char* label, const F& v) {
+        uint8_t b[32];
+        H::to_le_bytes(v, b);
+        tr.append_scalars(label, b, 1, 32, true);
+    }
+    F tr_challenge(const char* label) {
+        uint8_t b[32];
+        tr.challenge_scalar(label, R::BITS, b);
+        return H::from_le_bytes(b);
+    }
+    static void put(uint32_t dst[8], const F& v) { memcpy(dst, v.v, 32); }
+
+    int commit(const void* d_poly, size_t len, Affine<Q>* out) {
+        uint64_t xy[12];
+        int rc = msm_g1_dev(c, d_poly, len, 0, 1, xy, nullptr);
+        if (rc) return rc;
+        memcpy(out->x.v, xy, Q::N * 4);
+        memcpy(out->y.v, xy + Q::N / 2, Q::N * 4);
+        return ZKT_OK;
+    }
+
+    // iNTT of n evaluations into a zero-tailed coefficient buffer, trim, blind (prove.rs:120-127 etc.)
+    int evals_to_blinded_poly(const void* ev, void* poly, int blinder_off, int k, int len_slot) {
+        const size_t n = S.n;
+        int rc;
+        if ((rc = ntt_run(c, S.log_n, 1, 0, ev, n, poly))) return rc;
+        ZKT_HIP(c, hipMemsetAsync((char*)poly + n * 32, 0, 8 * 32, c->stream));
+        if (k > 0) {
+            if ((rc = poly_trim_len(c, poly, n, S.status + 8 + len_slot))) return rc;
+            if ((rc = poly_add_blinders(c, poly, S.status + 8 + len_slot, (const char*)S.small + (size_t)blinder_off * 32, k, n + 8)))
+                return rc;
+        }
+        return ZKT_OK;
+    }
+
+    int check_status() {
+        uint32_t st = 0;
+        ZKT_HIP(c, hipMemcpyAsync(&st, S.status, 4, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if (st & 4u) return set_err(c, ZKT_ERR_NOT_IN_TABLE, "ElementNotIndexedInTable: a looked-up value is not in the table");
+        if (st & 2u) return set_err(c, ZKT_ERR_QUOTIENT_TOO_SHORT, "quotient degree exceeds 3n+5: the circuit is not satisfied");
+        if (st & 1u) return set_err(c, ZKT_ERR_QUOTIENT_TOO_SHORT, "quotient polynomial too short to split (prove.rs:287-300)");
+        return ZKT_OK;
+    }
+
+    // lookup/multiset.rs:103-146 on the device; table = distinct values in insertion order
+    int combine_split(const uint64_t* table, size_t table_len) {
+        const size_t n = S.n;
+        std::vector<F> keys(table_len);
+        for (size_t i = 0; i < table_len; ++i) keys[i] = H::from_words(table + 4 * i);
+        std::vector<uint32_t> counts(table_len, 1u);
+        // t is padded with zeros to n (lookup/table.rs:52-61): they join the zero key or create it
+        size_t zero_idx = table_len;
+        for (size_t i = 0; i < table_len; ++i)
+            if (fe_is_zero<R>(keys[i])) {
+                zero_idx = i;
+                break;
+            }
+        if (n > table_len) {
+            if (zero_idx == table_len) {
+                keys.push_back(fe_zero<R>());
+                counts.push_back(0);
+            }
+            counts[zero_idx] += (uint32_t)(n - table_len);
+        }
+        const uint32_t nk = (uint32_t)keys.size();
+        if (nk + 2 > S.lk_cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "lookup table larger than the circuit bound");
+        std::vector<uint32_t> order(nk);
+        for (uint32_t i = 0; i < nk; ++i) order[i] = i;
+        auto less = [&](uint32_t a, uint32_t b) {
+            for (int i = R::N - 1; i >= 0; --i) {
+                if (keys[a].v[i] != keys[b].v[i]) return keys[a].v[i] < keys[b].v[i];
+            }
+            return false;
+        };
+        std::sort(order.begin(), order.end(), less);
+        std::vector<F> sorted(nk);
+        for (uint32_t i = 0; i < nk; ++i) sorted[i] = keys[order[i]];
+        F* d_keys = (F*)S.lk_keys;
+        F* d_sorted = d_keys + S.lk_cap;
+        uint32_t* d_perm = S.lk_u32;
+        uint32_t* d_counts = S.lk_u32 + S.lk_cap;
+        uint32_t* d_starts = S.lk_u32 + 2 * S.lk_cap;
+        ZKT_HIP(c, hipMemcpyAsync(d_keys, keys.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
+        ZKT_HIP(c, hipMemcpyAsync(d_sorted, sorted.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
+        ZKT_HIP(c, hipMemcpyAsync(d_perm, order.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
+        ZKT_HIP(c, hipMemcpyAsync(d_counts, counts.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
+        int rc;
+        if ((rc = lookup_count(c, S.ev[4], n, d_sorted, d_perm, nk, d_counts, S.status))) return rc;
+        ZKT_HIP(c, hipMemcpyAsync(counts.data(), d_counts, nk * 4, hipMemcpyDeviceToHost, c->stream));
+        if ((rc = check_status())) return rc;
+        // multiset.rs:126-143: halves and the alternating odd element
+        std::vector<uint32_t> s_even(nk + 1), s_odd(nk + 1);
+        uint32_t pe = 0, po = 0;
+        bool parity = false;
+        for (uint32_t k = 0; k < nk; ++k) {
+            s_even[k] = pe;
+            s_odd[k] = po;
+            uint32_t half = counts[k] / 2;
+            pe += half;
+            po += half;
+            if (counts[k] & 1u) {
+                if (parity) {
+                    po += 1;
+                    parity = false;
+                } else {
+                    pe += 1;
+                    parity = true;
+                }
+            }
+        }
+        s_even[nk] = pe;
+        s_odd[nk] = po;
+        if (pe != n || po != n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "combine_split: h1/h2 length differs from n");
+        ZKT_HIP(c, hipMemcpyAsync(d_starts, s_even.data(), (nk + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if ((rc = lookup_expand(c, d_keys, d_starts, nk, S.ev[5], n))) return rc;
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));  // s_even is reused by the driver's staging copy
+        ZKT_HIP(c, hipMemcpyAsync(d_starts, s_odd.data(), (nk + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if ((rc = lookup_expand(c, d_keys, d_starts, nk, S.ev[6], n))) return rc;
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        return ZKT_OK;
+    }
+
+    int run(const zkt_prove_inputs& in, std::vector<uint8_t>& proof) {
+        const size_t n = S.n;
+        const int log_n = S.log_n;
+        int rc;
+        if (in.n_rows > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "more rows than the circuit bound");
+        if (in.table_len >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "max table size is equal or larger than n");
+        if (n < 8) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "circuit bound below 8");
+        ZKT_HIP(c, hipMemsetAsync(S.status, 0, 64 * 4, c->stream));
+        ZKT_HIP(c, hipMemcpyAsync(S.small, in.blinders, 19 * 32, hipMemcpyHostToDevice, c->stream));
+
+        // prove.rs:110 -- public inputs (BTreeMap order = ascending position)
+        {
+            std::vector<uint8_t> b(in.n_pi * 32);
+            for (size_t i = 0; i < in.n_pi; ++i) H::to_le_bytes(H::from_words(in.pi_vals + 4 * i), b.data() + 32 * i);
+            tr.append_scalars("pi", b.data(), in.n_pi, 32, false);
+        }
+
+        // ---- round 1 (prove.rs:116-140) ----
+        const uint64_t* wires[3] = {in.a_evals, in.b_evals, in.c_evals};
+        for (int k = 0; k < 3; ++k) {
+            ZKT_HIP(c, hipMemsetAsync(S.ev[k], 0, n * 32, c->stream));
+            if (in.n_rows) ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32, hipMemcpyHostToDevice, c->stream));
+            if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
+        }
+        Affine<Q> cm[11];
+        static const char* L1[3] = {"a_commit", "b_commit", "c_commit"};
+        for (int k = 0; k < 3; ++k) {
+            if ((rc = commit(S.poly[k], n + 2, &cm[k]))) return rc;
+            tr_commit(L1[k], cm[k]);
+        }
+
+        // ---- round 2 (prove.rs:145-185) ----
+        ZKT_HIP(c, hipMemsetAsync(S.ev[3], 0, n * 32, c->stream));
+        if (in.table_len) ZKT_HIP(c, hipMemcpyAsync(S.ev[3], in.table, in.table_len * 32, hipMemcpyHostToDevice, c->stream));
+        if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;          // t: no blinders
+        if ((rc = poly_mul_vec(c, S.q_lookup_ev, S.ev[2], S.ev[4], n))) return rc;         // f = q_lookup . c
+        if ((rc = combine_split(in.table, in.table_len))) return rc;
+        if ((rc = evals_to_blinded_poly(S.ev[5], S.poly[4], 6, 3, 4))) return rc;          // h1: 3 blinders
+        if ((rc = evals_to_blinded_poly(S.ev[6], S.poly[5], 9, 2, 5))) return rc;          // h2: 2 blinders
+        if ((rc = commit(S.poly[3], n, &cm[3]))) return rc;
+        if ((rc = commit(S.poly[4], n + 3, &cm[4]))) return rc;
+        if ((rc = commit(S.poly[5], n + 2, &cm[5]))) return rc;
+        tr_commit("t_commit", cm[3]);
+        tr_commit("h1_commit", cm[4]);
+        tr_commit("h2_commit", cm[5]);
+
+        // ---- round 3 (prove.rs:190-255) ----
+        const F beta = tr_challenge("beta"), gamma = tr_challenge("gamma"), delta = tr_challenge("delta"),
+                epsilon = tr_challenge("epsilon");
+        if (fe_eq<R>(beta, gamma) || fe_eq<R>(beta, delta) || fe_eq<R>(beta, epsilon) || fe_eq<R>(gamma, delta) ||
+            fe_eq<R>(gamma, epsilon) || fe_eq<R>(delta, epsilon))
+            return set_err(c, ZKT_ERR_EQUAL_CHALLENGES, "challenges must be different (prove.rs:202-207)");
+        ZTermsArgs za{};
+        za.a = S.ev[0]; za.b = S.ev[1]; za.c = S.ev[2];
+        za.s1 = S.sigma_ev[0]; za.s2 = S.sigma_ev[1]; za.s3 = S.sigma_ev[2]; za.roots = S.roots;
+        za.f = S.ev[4]; za.t = S.ev[3]; za.h1 = S.ev[5]; za.h2 = S.ev[6];
+        za.num = S.sc[0]; za.den = S.sc[1]; za.n = n;
+        put(za.beta, beta); put(za.gamma, gamma); put(za.delta, delta); put(za.epsilon, epsilon);
+        F* pin = (F*)S.pinned;
+        // z1 into ev[7] (pi slot is filled later), z2 into sc[3] after use
+        if ((rc = z1_terms(c, za))) return rc;
+        if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;   // PN
+        if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;    // SD
+        ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the permutation grand product");
+        {
+            F inv = fe_inv<R>(pin[0]);
+            if ((rc = z_combine(c, S.sc[2], S.sc[3], inv.v, S.ev[7], n))) return rc;
+        }
+        if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[6], 11, 3, 6))) return rc;         // z1: 3 blinders
+        if ((rc = z2_terms(c, za))) return rc;
+        if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;
+        if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;
+        ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the lookup grand product");
+        {
+            F inv = fe_inv<R>(pin[0]);
+            if ((rc = z_combine(c, S.sc[2], S.sc[3], inv.v, S.ev[7], n))) return rc;
+        }
+        if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[7], 14, 3, 7))) return rc;         // z2: 3 blinders
+        if ((rc = commit(S.poly[6], n + 3, &cm[6]))) return rc;
+        if ((rc = commit(S.poly[7], n + 3, &cm[7]))) return rc;
+        tr_commit("z1_commit", cm[6]);
+        tr_commit("z2_commit", cm[7]);
+
+        // ---- round 4 (prove.rs:258-313) ----
+        ZKT_HIP(c, hipMemsetAsync(S.ev[7], 0, n * 32, c->stream));
+        for (size_t i = 0; i < in.n_pi; ++i) {
+            if (in.pi_pos[i] >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "public input position out of range");
+            ZKT_HIP(c, hipMemcpyAsync((char*)S.ev[7] + in.pi_pos[i] * 32, in.pi_vals + 4 * i, 32, hipMemcpyHostToDevice, c->stream));
+        }
+        if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[8], 0, 0, 8))) return rc;          // pi
+        const F alpha = tr_challenge("alpha");
+        {
+            // quotient_poly.rs:52-96 -- nine coset transforms on the 4n domain
+            const int src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
+            for (int k = 0; k < W_COUNT; ++k)
+                if ((rc = ntt_run(c, log_n + 2, 0, 1, S.poly[src[k]], n + 8, S.wcos[k]))) return rc;
+            QuotientArgs q{};
+            q.a = S.wcos[W_A]; q.b = S.wcos[W_B]; q.c = S.wcos[W_C]; q.pi = S.wcos[W_PI];
+            q.z1 = S.wcos[W_Z1]; q.z2 = S.wcos[W_Z2]; q.t = S.wcos[W_T]; q.h1 = S.wcos[W_H1]; q.h2 = S.wcos[W_H2];
+            q.q_m = S.coset[CS_QM]; q.q_l = S.coset[CS_QL]; q.q_r = S.coset[CS_QR]; q.q_o = S.coset[CS_QO];
+            q.q_c = S.coset[CS_QC]; q.q_lookup = S.coset[CS_QLOOKUP]; q.q_table = S.coset[CS_QTABLE];
+            q.sigma1 = S.coset[CS_S1]; q.sigma2 = S.coset[CS_S2]; q.sigma3 = S.coset[CS_S3];
+            q.x = S.coset[CS_X]; q.l1 = S.coset[CS_L1];
+            q.out = S.qev;
+            put(q.alpha, alpha); put(q.beta, beta); put(q.gamma, gamma); put(q.delta, delta); put(q.epsilon, epsilon);
+            memcpy(q.zh_inv, S.zh_inv, sizeof(q.zh_inv));
+            q.n4 = 4 * n;
+            if ((rc = quotient_pointwise(c, q))) return rc;
+            if ((rc = ntt_run(c, log_n + 2, 1, 1, S.qev, 4 * n, S.qev))) return rc;         // quotient_poly.rs:226
+            if ((rc = quotient_split_blind(c, S.qev, n, (const char*)S.small + 17 * 32, S.poly[9], S.poly[10], S.poly[11], S.status)))
+                return rc;
+            if ((rc = check_status())) return rc;
+        }
+        if ((rc = commit(S.poly[9], n + 3, &cm[8]))) return rc;
+        if ((rc = commit(S.poly[10], n + 3, &cm[9]))) return rc;
+        if ((rc = commit(S.poly[11], n + 3, &cm[10]))) return rc;
+        tr_commit("q_lo_commit", cm[8]);
+        tr_commit("q_mid_commit", cm[9]);
+        tr_commit("q_hi_commit", cm[10]);
+
+        // ---- round 5 (prove.rs:318-451, linearization_poly.rs:19-121) ----
+        const F xi = tr_challenge("xi");
+        F w;
+        {
+            Fe<R> g = root_of_unity<R>(log_n);
+            w = g;
+        }
+        const F shifted = fe_mul<R>(xi, w);
+        const size_t cap = n + 8;
+        EvalArgs ea{};
+        // order of ProofEvaluations: a b c | sigma1 sigma2 z1_next | q_lookup t t_next z2_next h1_next h2
+        const void* ep[12] = {S.poly[0], S.poly[1], S.poly[2], S.pk[PK_S1], S.pk[PK_S2], S.poly[6],
+                              S.pk[PK_QLOOKUP], S.poly[3], S.poly[3], S.poly[7], S.poly[4], S.poly[5]};
+        const size_t el[12] = {cap, cap, cap, S.pk_len[PK_S1], S.pk_len[PK_S2], cap, S.pk_len[PK_QLOOKUP], cap, cap, cap, cap, cap};
+        const bool sh[12] = {false, false, false, false, false, true, false, false, true, true, true, false};
+        ea.count = 12;
+        for (int k = 0; k < 12; ++k) {
+            ea.poly[k] = ep[k];
+            ea.len[k] = el[k];
+            put(ea.point[k], sh[k] ? shifted : xi);
+        }
+        void* d_partials = (char*)S.small + 64 * 32;
+        void* d_results = (char*)S.small + 32 * 32;
+        if ((rc = poly_eval_many(c, ea, d_partials, d_results))) return rc;
+        ZKT_HIP(c, hipMemcpyAsync(pin, d_results, 12 * 32, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        F ev[12];
+        for (int k = 0; k < 12; ++k) ev[k] = pin[k];
+        const F &e_a = ev[0], &e_b = ev[1], &e_c = ev[2], &e_s1 = ev[3], &e_s2 = ev[4], &e_z1n = ev[5], &e_ql = ev[6],
+                &e_t = ev[7], &e_tn = ev[8], &e_z2n = ev[9], &e_h1n = ev[10], &e_h2 = ev[11];
+        const F one = fe_one<R>();
+        // zh(xi) = xi^n - 1 ; L_1(xi) = zh * 1 / (n * (xi - 1))   (util.rs:185-195)
+        const F xi_n = fe_pow_u64<R>(xi, (uint64_t)n);
+        const F zh = fe_sub<R>(xi_n, one);
+        F nn = fe_zero<R>();
+        nn.v[0] = (uint32_t)(n & 0xffffffffu);
+        nn.v[1] = (uint32_t)((uint64_t)n >> 32);
+        nn = fe_to_mont<R>(nn);
+        const F l1den = fe_mul<R>(nn, fe_sub<R>(xi, one));
+        if (fe_is_zero<R>(l1den)) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "xi = 1");
+        const F l1 = fe_mul<R>(zh, fe_inv<R>(l1den));
+        const F a2 = fe_sqr<R>(alpha), a3 = fe_mul<R>(a2, alpha), a4 = fe_mul<R>(a3, alpha), a5 = fe_mul<R>(a4, alpha);
+        const F k1 = fe_from_u32<R>(7), k2 = fe_from_u32<R>(13);
+        const F bxi = fe_mul<R>(beta, xi);
+        // keys/permutation.rs:34-69
+        F s_z1 = fe_mul<R>(alpha, fe_add<R>(fe_add<R>(bxi, e_a), gamma));
+        s_z1 = fe_mul<R>(s_z1, fe_add<R>(fe_add<R>(fe_mul<R>(bxi, k1), e_b), gamma));
+        s_z1 = fe_mul<R>(s_z1, fe_add<R>(fe_add<R>(fe_mul<R>(bxi, k2), e_c), gamma));
+        s_z1 = fe_add<R>(s_z1, fe_mul<R>(l1, a2));
+        F s_s3 = fe_mul<R>(fe_neg<R>(alpha), beta);
+        s_s3 = fe_mul<R>(s_s3, e_z1n);
+        s_s3 = fe_mul<R>(s_s3, fe_add<R>(fe_add<R>(fe_mul<R>(beta, e_s1), e_a), gamma));
+        s_s3 = fe_mul<R>(s_s3, fe_add<R>(fe_add<R>(fe_mul<R>(beta, e_s2), e_b), gamma));
+        // keys/lookup.rs:29-65
+        const F opd = fe_add<R>(delta, one), eopd = fe_mul<R>(epsilon, opd);
+        F s_z2 = fe_mul<R>(a3, opd);
+        s_z2 = fe_mul<R>(s_z2, fe_add<R>(epsilon, fe_mul<R>(e_ql, e_c)));
+        s_z2 = fe_mul<R>(s_z2, fe_add<R>(fe_add<R>(eopd, e_t), fe_mul<R>(delta, e_tn)));
+        s_z2 = fe_add<R>(s_z2, fe_mul<R>(a4, l1));
+        F s_h1 = fe_mul<R>(fe_neg<R>(a3), e_z2n);
+        s_h1 = fe_mul<R>(s_h1, fe_add<R>(fe_add<R>(eopd, e_h2), fe_mul<R>(delta, e_h1n)));
+        const F s_qt = fe_mul<R>(a5, e_t);
+        // linearization_poly.rs:100-109: -zh * (q_lo + xi^(n+2) q_mid + xi^(2n+4) q_hi)
+        const F xn2 = fe_mul<R>(fe_mul<R>(fe_add<R>(zh, one), xi), xi);
+        const F nzh = fe_neg<R>(zh);
+        LinCombArgs lr{};
+        auto term = [&](LinCombArgs& L, const void* p, size_t len, const F& s) {
+            L.poly[L.nterms] = p;
+            L.len[L.nterms] = len;
+            put(L.scalar[L.nterms], s);
+            ++L.nterms;
+        };
+        term(lr, S.pk[PK_QM], S.pk_len[PK_QM], fe_mul<R>(e_a, e_b));   // keys/arithmetic.rs:37-46
+        term(lr, S.pk[PK_QL], S.pk_len[PK_QL], e_a);
+        term(lr, S.pk[PK_QR], S.pk_len[PK_QR], e_b);
+        term(lr, S.pk[PK_QO], S.pk_len[PK_QO], e_c);
+        term(lr, S.pk[PK_QC], S.pk_len[PK_QC], one);
+        term(lr, S.poly[6], cap, s_z1);
+        term(lr, S.pk[PK_S3], S.pk_len[PK_S3], s_s3);
+        term(lr, S.poly[7], cap, s_z2);
+        term(lr, S.poly[4], cap, s_h1);
+        term(lr, S.pk[PK_QTABLE], S.pk_len[PK_QTABLE], s_qt);
+        term(lr, S.poly[9], cap, nzh);
+        term(lr, S.poly[10], cap, fe_mul<R>(nzh, xn2));
+        term(lr, S.poly[11], cap, fe_mul<R>(nzh, fe_sqr<R>(xn2)));
+        static const char* EL[12] = {"a_eval", "b_eval", "c_eval", "sigma1_eval", "sigma2_eval", "z1_next_eval",
+                                     "q_lookup_eval", "t_eval", "t_next_eval", "z2_next_eval", "h1_next_eval", "h2_eval"};
+        for (int k = 0; k < 12; ++k) tr_scalar(EL[k], ev[k]);
+        const F eta = tr_challenge("eta");
+        // r(X) lives in the work buffer; its own commitment (prove.rs:372-375) is never part of the proof
+        // or the transcript, so it is not computed.
+        // aw opening (prove.rs:381-420): sum_k eta^k p_k over (r, a, b, c, sigma1, sigma2, q_lookup, t, h2)
+        // = eta^0 * r + ... : fold r's 13 terms and the 8 others into two passes
+        void* work = S.poly[12];
+        if ((rc = poly_lincomb(c, lr, work, cap))) return rc;
+        if (fe_is_zero<R>(xi) || fe_is_zero<R>(shifted)) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "evaluation challenge is zero");
+        Affine<Q> aw, saw;
+        {
+            LinCombArgs lo{};
+            F pw = one;
+            term(lo, work, cap, pw);
+            const void* ps[8] = {S.poly[0], S.poly[1], S.poly[2], S.pk[PK_S1], S.pk[PK_S2], S.pk[PK_QLOOKUP], S.poly[3], S.poly[5]};
+            const size_t pl[8] = {cap, cap, cap, S.pk_len[PK_S1], S.pk_len[PK_S2], S.pk_len[PK_QLOOKUP], cap, cap};
+            for (int k = 0; k < 8; ++k) {
+                pw = fe_mul<R>(pw, eta);
+                term(lo, ps[k], pl[k], pw);
+            }
+            void* comb = S.sc[0];  // n + 8 fits: sc buffers hold n + 8 elements
+            if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
+            F zi = fe_inv<R>(xi);
+            if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
+            if ((rc = commit(S.sc[3], cap - 1, &aw))) return rc;
+        }
+        {   // saw opening (prove.rs:427-451): (z1, z2, t, h1) at xi * omega
+            LinCombArgs lo{};
+            F pw = one;
+            const void* ps[4] = {S.poly[6], S.poly[7], S.poly[3], S.poly[4]};
+            for (int k = 0; k < 4; ++k) {
+                term(lo, ps[k], cap, pw);
+                pw = fe_mul<R>(pw, eta);
+            }
+            void* comb = S.sc[0];
+            if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
+            F zi = fe_inv<R>(shifted);
+            if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
+            if ((rc = commit(S.sc[3], cap - 1, &saw))) return rc;
+        }
+
+        // ---- Proof (proof.rs:106-155), CanonicalSerialize ----
+        proof.clear();
+        for (int k = 0; k < 11; ++k) serialize_point<Q>(cm[k], proof);
+        serialize_point<Q>(aw, proof);
+        proof.push_back(0);   // kzg10::Proof::random_v = None
+        serialize_point<Q>(saw, proof);
+        proof.push_back(0);
+        for (int k = 0; k < 12; ++k) {
+            uint8_t b[32];
+            H::to_le_bytes(ev[k], b);
+            proof.insert(proof.end(), b, b + 32);
+        }
+        return ZKT_OK;
+    }
+};
+
+// ---- circuit (ProverKey + ExtendedProverKey) ------------------------------------------------------
+static void circuit_release(zkt_ctx* c) {
+    if (!c->circuit) return;
+    (void)hipStreamSynchronize(c->stream);
+    CircuitState& S = *c->circuit;
+    auto fr = [&](void* p) { dev_free(c, p); };
+    for (void* p : S.pk) fr(p);
+    for (void* p : S.coset) fr(p);
+    for (void* p : S.sigma_ev) fr(p);
+    fr(S.q_lookup_ev); fr(S.roots);
+    for (void* p : S.ev) fr(p);
+    for (void* p : S.sc) fr(p);
+    fr(S.scan_tmp);
+    for (void* p : S.poly) fr(p);
+    for (void* p : S.wcos) fr(p);
+    fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys);
+    if (S.pinned) (void)hipHostFree(S.pinned);
+    c->circuit.reset();
+}
+
+template <class C>
+static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, const size_t* lens) {
+    using R = typename C::Fr;
+    using F = Fe<R>;
+    if (log_n < 3 || log_n + 2 > R::TWO_ADICITY || log_n + 2 > 27)
+        return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize: 4n domain unsupported");
+    circuit_release(c);
+    auto st = std::make_shared<CircuitState>();
+    CircuitState& S = *st;
+    S.log_n = log_n;
+    const size_t n = (size_t)1 << log_n;
+    S.n = n;
+    int rc;
+    auto alloc = [&](void** p, size_t elems) { return dev_alloc(c, p, elems * 32); };
+    for (int k = 0; k < PK_COUNT; ++k) {
+        if (lens[k] > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "prover-key polynomial longer than n");
+        if ((rc = alloc(&S.pk[k], n))) return rc;
+        ZKT_HIP(c, hipMemsetAsync(S.pk[k], 0, n * 32, c->stream));
+        if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.pk[k], polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
+        S.pk_len[k] = lens[k];
+    }
+    for (int k = 0; k < CS_COUNT; ++k) if ((rc = alloc(&S.coset[k], 4 * n))) return rc;
+    for (int k = 0; k < 3; ++k) if ((rc = alloc(&S.sigma_ev[k], n))) return rc;
+    if ((rc = alloc(&S.q_lookup_ev, n))) return rc;
+    if ((rc = alloc(&S.roots, n))) return rc;
+    for (auto& p : S.ev) if ((rc = alloc(&p, n + 8))) return rc;
+    for (auto& p : S.sc) if ((rc = alloc(&p, n + 8))) return rc;
+    if ((rc = alloc(&S.scan_tmp, 2 * ((n + 8) / 1024 + 4096)))) return rc;
+    for (auto& p : S.poly) if ((rc = alloc(&p, n + 8))) return rc;
+    for (auto& p : S.wcos) if ((rc = alloc(&p, 4 * n))) return rc;
+    if ((rc = alloc(&S.qev, 4 * n))) return rc;
+    const size_t eval_blocks = (n + 8 + 2047) / 2048 + 1;
+    if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
+    if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
+    S.lk_cap = n + 2;
+    if ((rc = dev_alloc(c, (void**)&S.lk_u32, 3 * S.lk_cap * 4 + 16))) return rc;
+    if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
+    ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
+
+    // extend_prover_key (keys/mod.rs:78-146) on the device
+    const int pk_of_cs[10] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, PK_QLOOKUP, PK_QTABLE, PK_S1, PK_S2, PK_S3};
+    for (int k = 0; k < 10; ++k)
+        if ((rc = ntt_run(c, log_n + 2, 0, 1, S.pk[pk_of_cs[k]], n, S.coset[k]))) return rc;
+    // sigma / q_lookup evaluations on the n domain (prove.rs:91-94)
+    if ((rc = ntt_run(c, log_n, 0, 0, S.pk[PK_S1], n, S.sigma_ev[0]))) return rc;
+    if ((rc = ntt_run(c, log_n, 0, 0, S.pk[PK_S2], n, S.sigma_ev[1]))) return rc;
+    if ((rc = ntt_run(c, log_n, 0, 0, S.pk[PK_S3], n, S.sigma_ev[2]))) return rc;
+    if ((rc = ntt_run(c, log_n, 0, 0, S.pk[PK_QLOOKUP], n, S.q_lookup_ev))) return rc;
+    const F one = fe_one<R>();
+    const F w = root_of_unity<R>(log_n), w4n = root_of_unity<R>(log_n + 2);
+    const F g = fe_from_u32<R>(R::GENERATOR);
+    if ((rc = gen_powers(c, S.roots, n, w.v, one.v))) return rc;                 // domain.elements()
+    if ((rc = gen_powers(c, S.coset[CS_X], 4 * n, w4n.v, g.v))) return rc;       // x_coset = g * w4n^i (keys/mod.rs:110-113)
+    {   // l_1_coset = coset_fft(L_1), L_1 = ifft(1, 0, ..., 0) = (1/n, ..., 1/n)  (keys/mod.rs:119-120)
+        F nn = fe_zero<R>();
+        nn.v[0] = (uint32_t)(n & 0xffffffffu);
+        nn.v[1] = (uint32_t)((uint64_t)n >> 32);
+        F ninv = fe_inv<R>(fe_to_mont<R>(nn));
+        if ((rc = gen_powers(c, S.ev[0], n, one.v, ninv.v))) return rc;
+        if ((rc = ntt_run(c, log_n + 2, 0, 1, S.ev[0], n, S.coset[CS_L1]))) return rc;
+    }
+    {   // zh_coset takes four values: (g * w4n^i)^n - 1 = g^n * w4^(i mod 4) - 1   (keys/mod.rs:115-117)
+        const F gn = fe_pow_u64<R>(g, (uint64_t)n);
+        const F w4 = fe_pow_u64<R>(w4n, (uint64_t)n);
+        F cur = gn;
+        for (int j = 0; j < 4; ++j) {
+            F zh = fe_sub<R>(cur, one);
+            if (fe_is_zero<R>(zh)) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "vanishing polynomial is zero on the coset");
+            F inv = fe_inv<R>(zh);
+            memcpy(S.zh_inv[j], inv.v, 32);
+            cur = fe_mul<R>(cur, w4);
+        }
+    }
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    c->circuit = st;
+    return ZKT_OK;
+}
+
+struct VtableTranscript;  // capi glue below
+
+}  // namespace zkt
+
+using namespace zkt;
+
+struct zkt_transcript {
+    std::unique_ptr<HostTranscript> impl;
+    Merlin* merlin = nullptr;  // raw access for the conformance KAT
+};
+
+namespace zkt {
+// Adapter over a foreign transcript (the Rust shim's `T: TranscriptProtocol`): values cross in
+// arkworks' Montgomery limbs, exactly what the shim can hand to T::append_scalar / append_commitment.
+template <class C>
+struct VtableAdapter : HostTranscript {
+    using R = typename C::Fr;
+    using Q = typename C::Fq;
+    const zkt_transcript_vtable* vt;
+    explicit VtableAdapter(const zkt_transcript_vtable* v) : vt(v) {}
+    void append_u64(const char* label, uint64_t v) override { vt->append_u64(vt->user, label, v); }
+    void append_scalars(const char* label, const uint8_t* le, size_t count, size_t, bool single) override {
+        std::vector<uint64_t> m(4 * count);
+        for (size_t i = 0; i < count; ++i) {
+            Fe<R> x = HostF<R>::from_le_bytes(le + 32 * i);
+            memcpy(&m[4 * i], x.v, 32);
+        }
+        vt->append_scalars(vt->user, label, m.data(), count, single ? 1 : 0);
+    }
+    void append_commitment(const char* label, const uint8_t* x_le, const uint8_t* y_le, size_t, bool inf) override {
+        uint64_t xy[12] = {0};
+        if (!inf) {
+            Fe<Q> x, y;
+            memcpy(x.v, x_le, Q::N * 4);
+            memcpy(y.v, y_le, Q::N * 4);
+            x = fe_to_mont<Q>(x);
+            y = fe_to_mont<Q>(y);
+            memcpy(xy, x.v, Q::N * 4);
+            memcpy(xy + Q::N / 2, y.v, Q::N * 4);
+        }
+        vt->append_commitment(vt->user, label, xy, inf ? 1 : 0);
+    }
+    void challenge_scalar(const char* label, size_t, uint8_t out_le[32]) override {
+        uint64_t m[4];
+        vt->challenge_scalar(vt->user, label, m);
+        HostF<R>::to_le_bytes(HostF<R>::from_words(m), out_le);
+    }
+};
+}  // namespace zkt
+
+extern "C" {
+
+zkt_transcript* zkt_transcript_new(int kind, const char* label) {
+    zkt_transcript* t = new zkt_transcript();
+    if (kind == ZKT_TRANSCRIPT_MERLIN) {
+        auto* m = new MerlinHostTranscript(label ? label : "");
+        t->merlin = &m->t;
+        t->impl.reset(m);
+    } else if (kind == ZKT_TRANSCRIPT_ETHEREUM) {
+        t->impl.reset(new EthereumHostTranscript());
+    } else {
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void zkt_transcript_free(zkt_transcript* t) { delete t; }
+void zkt_transcript_append_u64(zkt_transcript* t, const char* label, uint64_t v) { t->impl->append_u64(label, v); }
+void zkt_transcript_append_scalars(zkt_transcript* t, const char* label, const uint8_t* le32, size_t count, int single) {
+    t->impl->append_scalars(label, le32, count, 32, single != 0);
+}
+void zkt_transcript_append_commitment(zkt_transcript* t, const char* label, const uint8_t* x_le, const uint8_t* y_le,
+                                      size_t fq_bytes, int is_infinity) {
+    t->impl->append_commitment(label, x_le, y_le, fq_bytes, is_infinity != 0);
+}
+void zkt_transcript_challenge_scalar(zkt_transcript* t, const char* label, int fr_bits, uint8_t out_le32[32]) {
+    t->impl->challenge_scalar(label, (size_t)fr_bits, out_le32);
+}
+int zkt_transcript_challenge_bytes(zkt_transcript* t, const char* label, uint8_t* out, size_t len) {
+    if (!t->merlin) return ZKT_ERR_INVALID_ARGUMENT;
+    t->merlin->challenge_bytes(label, out, len);
+    return ZKT_OK;
+}
+int zkt_transcript_append_message(zkt_transcript* t, const char* label, const uint8_t* msg, size_t len) {
+    if (!t->merlin) return ZKT_ERR_INVALID_ARGUMENT;
+    t->merlin->append_message(label, msg, len);
+    return ZKT_OK;
+}
+
+int zkt_circuit_load(zkt_ctx* c, int log_n, const uint64_t* const* pk_polys, const size_t* pk_lens) {
+    if (!c || !pk_polys || !pk_lens) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    if (c->curve == ZKT_CURVE_BN254) return circuit_load_t<Bn254Curve>(c, log_n, pk_polys, pk_lens);
+    return circuit_load_t<Bls381Curve>(c, log_n, pk_polys, pk_lens);
+}
+
+static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr, uint8_t* out, size_t cap, size_t* len) {
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    (void)hipSetDevice(c->device);
+    std::vector<uint8_t> proof;
+    int rc;
+    if (c->curve == ZKT_CURVE_BN254) {
+        Prover<Bn254Curve> p(c, *c->circuit, tr);
+        rc = p.run(*in, proof);
+    } else {
+        Prover<Bls381Curve> p(c, *c->circuit, tr);
+        rc = p.run(*in, proof);
+    }
+    if (rc) return rc;
+    if (len) *len = proof.size();
+    if (proof.size() > cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "proof buffer too small");
+    memcpy(out, proof.data(), proof.size());
+    return ZKT_OK;
+}
+
+int zkt_prove(zkt_ctx* c, const zkt_prove_inputs* in, zkt_transcript* tr, uint8_t* proof_out, size_t proof_cap,
+              size_t* proof_len) {
+    if (!c || !in || !tr || !proof_out) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    return prove_impl(c, in, *tr->impl, proof_out, proof_cap, proof_len);
+}
+
+int zkt_prove_with(zkt_ctx* c, const zkt_prove_inputs* in, const zkt_transcript_vtable* vt, uint8_t* proof_out,
+                   size_t proof_cap, size_t* proof_len) {
+    if (!c || !in || !vt || !proof_out) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (c->curve == ZKT_CURVE_BN254) {
+        VtableAdapter<Bn254Curve> a(vt);
+        return prove_impl(c, in, a, proof_out, proof_cap, proof_len);
+    }
+    VtableAdapter<Bls381Curve> a(vt);
+    return prove_impl(c, in, a, proof_out, proof_cap, proof_len);
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+"""Host-side mirror of the reference's prover entry points.
+
+* ``seed_transcript``  ~ ``VerifierKey::seed_transcript`` (plonk-core/src/proof_system/keys/mod.rs:260-275)
+* ``GpuProver.prove``  ~ ``ZKTPlonk::prove`` -> ``proof_system::prove`` (plonk-core/src/plonk.rs:94-111,
+  plonk-core/src/proof_system/prove.rs:59-470) with the circuit already synthesised into wire values.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from ._lib import Context, Transcript
+
+PK_ORDER = ("q_m", "q_l", "q_r", "q_o", "q_c", "sigma1", "sigma2", "sigma3", "q_lookup", "q_table")
+NUM_BLINDERS = 19  # a(2) b(2) c(2) h1(3) h2(2) z1(3) z2(3) b0 b1 -- prove.rs:125-127,170-171,225,244,296
+
+
+def seed_transcript(tr: Transcript, n: int, vk_commits: Dict[str, Optional[tuple]]) -> Transcript:
+    """keys/mod.rs:260-275; vk_commits maps the PK_ORDER names to affine points (canonical ints) or None."""
+    tr.append_u64("circuit_size", n)
+    for name in PK_ORDER:
+        tr.append_commitment(name + "_commit", vk_commits[name])
+    return tr
+
+
+class GpuProver:
+    """Device-resident circuit + SRS; one instance per (circuit, context)."""
+
+    def __init__(self, ctx: Context, log_n: int, pk_polys: Dict[str, np.ndarray]):
+        self.ctx = ctx
+        self.log_n = log_n
+        self.n = 1 << log_n
+        ctx.circuit_load(log_n, [pk_polys[k] for k in PK_ORDER])
+
+    def prove(self, a, b, c, table, public_inputs: Dict[int, np.ndarray], blinders, transcript: Transcript) -> bytes:
+        pos = sorted(public_inputs.keys())
+        vals = np.stack([np.asarray(public_inputs[p], dtype=np.uint64).reshape(4) for p in pos]) if pos else \
+            np.zeros((0, 4), dtype=np.uint64)
+        return self.ctx.prove(a, b, c, table, pos, vals, blinders, transcript)
