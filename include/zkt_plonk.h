@@ -61,6 +61,10 @@ const char* zkt_last_error(const zkt_ctx* ctx);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) for every launch of this context. */
 int zkt_ctx_set_stream(zkt_ctx* ctx, void* hip_stream);
 int zkt_ctx_synchronize(zkt_ctx* ctx);
+/* Per-kernel timing with HIP events on the context's stream (the stream the kernels run on).
+ * Names: "ntt_<log2 size>" (whole transform), "ntt_pass", "msm", "msm_accumulate", "quotient". */
+int zkt_profile_enable(zkt_ctx* ctx, int on);
+int zkt_profile_get(zkt_ctx* ctx, const char* name, uint64_t* calls, double* total_ms);
 const char* zkt_version(void);
 
 /* ---- device memory helpers (plumbing for callers without their own allocator) -------------- */
@@ -165,6 +169,8 @@ typedef struct {
     /* the 19 F::rand(rng) draws of prove.rs in reference order:
      * a(2) b(2) c(2) h1(3) h2(2) z1(3) z2(3) b0 b1   (prove.rs:125-127,170-171,225,244,296) */
     const uint64_t* blinders;
+    /* non-zero: a_evals / b_evals / c_evals are DEVICE pointers (witness already resident in HBM) */
+    int wires_on_device;
 } zkt_prove_inputs;
 
 /* Runs the five prover rounds on the device and writes the CanonicalSerialize bytes of

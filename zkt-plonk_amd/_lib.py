@@ -58,6 +58,8 @@ def lib():
         L.zkt_ctx_destroy.restype = None
         L.zkt_ctx_set_stream.argtypes = [vp, vp]
         L.zkt_ctx_synchronize.argtypes = [vp]
+        L.zkt_profile_enable.argtypes = [vp, ctypes.c_int]
+        L.zkt_profile_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
         L.zkt_dev_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
         L.zkt_dev_free.argtypes = [vp, vp]
         L.zkt_dev_upload.argtypes = [vp, vp, vp, ctypes.c_size_t]
@@ -92,7 +94,8 @@ class ProveInputs(ctypes.Structure):
                 ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),
                 ("table", ctypes.POINTER(ctypes.c_uint64)), ("table_len", ctypes.c_size_t),
                 ("pi_pos", ctypes.POINTER(ctypes.c_size_t)), ("pi_vals", ctypes.POINTER(ctypes.c_uint64)),
-                ("n_pi", ctypes.c_size_t), ("blinders", ctypes.POINTER(ctypes.c_uint64))]
+                ("n_pi", ctypes.c_size_t), ("blinders", ctypes.POINTER(ctypes.c_uint64)),
+                ("wires_on_device", ctypes.c_int)]
 
 
 def _bind_prover(L):
@@ -211,6 +214,15 @@ class Context:
     def synchronize(self):
         self.check(self._L.zkt_ctx_synchronize(self._h))
 
+    def profile_enable(self, on: bool = True):
+        self.check(self._L.zkt_profile_enable(self._h, int(on)))
+
+    def profile_get(self, name: str):
+        """-> (launch count, total milliseconds) measured with HIP events on the context's stream."""
+        calls, ms = ctypes.c_uint64(0), ctypes.c_double(0.0)
+        self.check(self._L.zkt_profile_get(self._h, name.encode(), ctypes.byref(calls), ctypes.byref(ms)))
+        return calls.value, ms.value
+
     # -- device memory ------------------------------------------------------------------------
     def alloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()
@@ -291,6 +303,21 @@ class Context:
         lens = (ctypes.c_size_t * 10)(*[a.shape[0] for a in arrs])
         self.check(self._L.zkt_circuit_load(self._h, log_n, ptrs, lens))
 
+    def prove_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
+        """Same as prove() with the three wire vectors already resident in HBM (device pointers)."""
+        table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+        pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
+        blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
+        pos = (ctypes.c_size_t * max(1, len(pi_pos)))(*pi_pos)
+        null = ctypes.POINTER(ctypes.c_uint64)()
+        cast = lambda p: ctypes.cast(ctypes.c_void_p(p), ctypes.POINTER(ctypes.c_uint64))
+        inp = ProveInputs(cast(d_a), cast(d_b), cast(d_c), n_rows, u64p(table) if table.size else null, table.shape[0],
+                          pos, u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 1)
+        out = (ctypes.c_uint8 * 2048)()
+        n = ctypes.c_size_t(0)
+        self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))
+        return bytes(out[:n.value])
+
     def prove(self, a, b, c, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
         """proof_system::prove (prove.rs:59-470); all arrays are (len, 4) Montgomery uint64."""
         a, b, c = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c))
@@ -301,7 +328,7 @@ class Context:
         null = ctypes.POINTER(ctypes.c_uint64)()
         inp = ProveInputs(u64p(a) if a.size else null, u64p(b) if b.size else null, u64p(c) if c.size else null,
                           a.shape[0], u64p(table) if table.size else null, table.shape[0], pos,
-                          u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders))
+                          u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 0)
         out = (ctypes.c_uint8 * 2048)()
         n = ctypes.c_size_t(0)
         self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))

@@ -44,6 +44,42 @@ int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes) {
     return ZKT_OK;
 }
 
+static hipEvent_t prof_event(zkt_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(zkt_ctx* ctx, const char* name) : c(ctx) {
+    if (!c->prof_on) return;
+    slot = &c->prof[name];
+    e0 = prof_event(c);
+    e1 = prof_event(c);
+    (void)hipEventRecord(e0, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (!slot) return;
+    (void)hipEventRecord(e1, c->stream);
+    slot->pending.emplace_back(e0, e1);
+    slot->calls += 1;
+}
+static void prof_resolve(zkt_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->prof) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
 template <class P>
 __global__ void k_fr_mul(const Fe<P>* a, const Fe<P>* b, Fe<P>* o, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -93,6 +129,9 @@ void zkt_ctx_destroy(zkt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    prof_resolve(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->event_pool.clear();
     c->ntt_plans.clear();
     c->msm.reset();
     c->circuit.reset();
@@ -110,6 +149,27 @@ int zkt_ctx_set_stream(zkt_ctx* c, void* hip_stream) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
+    return ZKT_OK;
+}
+
+int zkt_profile_enable(zkt_ctx* c, int on) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    prof_resolve(c);
+    if (on) c->prof.clear();
+    c->prof_on = on != 0;
+    return ZKT_OK;
+}
+int zkt_profile_get(zkt_ctx* c, const char* name, uint64_t* calls, double* total_ms) {
+    if (!c || !name || !calls || !total_ms) return ZKT_ERR_INVALID_ARGUMENT;
+    prof_resolve(c);
+    auto it = c->prof.find(name);
+    if (it == c->prof.end()) {
+        *calls = 0;
+        *total_ms = 0.0;
+        return ZKT_OK;
+    }
+    *calls = it->second.calls;
+    *total_ms = it->second.total_ms;
     return ZKT_OK;
 }
 

@@ -37,6 +37,16 @@ struct zkt_ctx {
     void* io_b = nullptr;
     size_t io_b_bytes = 0;
 
+    // optional per-kernel HIP-event timing (bench.py's live roofline measurement)
+    bool prof_on = false;
+    struct ProfSlot {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+        double total_ms = 0.0;
+        uint64_t calls = 0;
+    };
+    std::map<std::string, ProfSlot> prof;
+    std::vector<hipEvent_t> event_pool;
+
     std::shared_ptr<zkt::MsmState> msm;
     std::shared_ptr<zkt::CircuitState> circuit;
     std::vector<void*> owned;  // every hipMalloc made on behalf of this ctx
@@ -52,6 +62,16 @@ int hip_fail(zkt_ctx* c, hipError_t e, const char* what);
         hipError_t _e = (call);                                 \
         if (_e != hipSuccess) return zkt::hip_fail((c), _e, #call); \
     } while (0)
+
+// Records a start/stop HIP event pair on the context's stream around a launch (or a group of
+// launches) when profiling is on; durations are resolved lazily by zkt_profile_get.
+struct ProfScope {
+    zkt_ctx* c;
+    zkt_ctx::ProfSlot* slot = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(zkt_ctx* ctx, const char* name);
+    ~ProfScope();
+};
 
 // grows *p to at least `bytes`
 int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes);

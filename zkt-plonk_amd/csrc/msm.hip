@@ -503,6 +503,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     using R = typename C::Fr;
     MsmState& st = *c->msm;
     const uint32_t m = (uint32_t)((size_t)st.W * n);
+    ProfScope prof_all(c, "msm");
     {
         unsigned blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_msm_digits<C>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<R>*)d_scalars, n, mont,
@@ -516,6 +517,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
                        st.offsets);
     ZKT_HIP(c, hipGetLastError());
     {
+        ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.keys2,
                            st.vals2, m, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);

@@ -437,6 +437,8 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
         it = c->ntt_plans.emplace(key, std::static_pointer_cast<void>(holder)).first;
     }
     const NttPlan<P>& pl = *static_cast<const NttPlan<P>*>(it->second.get());
+    const std::string prof_name = "ntt_" + std::to_string(log_n);  // e.g. "ntt_20", "ntt_22"
+    ProfScope prof_all(c, prof_name.c_str());
     if (pl.npass == 0) {
         hipLaunchKernelGGL(k_ntt_small<P>, dim3(1), dim3(NTT_THREADS), 0, c->stream, (const Fe<P>*)d_in,
                            (uint64_t)in_len, (Fe<P>*)d_out, log_n, (const Fe<P>*)pl.small_w,
@@ -461,6 +463,7 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
         a.in_len = (i == 0) ? (uint64_t)in_len : N;
         a.log_n = (uint32_t)log_n;
         acc += pl.log_r[i];
+        ProfScope prof_pass(c, "ntt_pass");
         if (!last) {
             a.log_s = (uint32_t)(log_n - acc);
             launch_pass<P, false>(c, pl.log_r[i], blocks, a);

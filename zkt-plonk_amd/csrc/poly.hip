@@ -525,6 +525,7 @@ template <class P> static int z_combine_t(zkt_ctx* c, const void* pn, const void
 int z_combine(zkt_ctx* c, const void* pn, const void* sd, const uint32_t inv_total[8], void* out, size_t n) { ZKT_DISPATCH(c, z_combine_t, pn, sd, inv_total, out, n); }
 
 template <class P> static int quotient_t(zkt_ctx* c, const QuotientArgs& a) {
+    ProfScope prof(c, "quotient");
     hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(a.n4)), dim3(256), 0, c->stream, a);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;

@@ -263,7 +263,9 @@ struct Prover {
         const uint64_t* wires[3] = {in.a_evals, in.b_evals, in.c_evals};
         for (int k = 0; k < 3; ++k) {
             ZKT_HIP(c, hipMemsetAsync(S.ev[k], 0, n * 32, c->stream));
-            if (in.n_rows) ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32, hipMemcpyHostToDevice, c->stream));
+            if (in.n_rows)
+                ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32,
+                                          in.wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
             if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
         }
         Affine<Q> cm[11];
