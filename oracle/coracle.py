@@ -30,9 +30,18 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def _cpu_share() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))  # a one-GPU box grants a 16-CPU share whatever the host's core count
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_share()))
         if not os.path.exists(_LIB_PATH):
             build()
         L = ctypes.CDLL(_LIB_PATH)
