@@ -189,9 +189,10 @@ def main():
         return ctx.prove_dev(wires[0].data_ptr(), wires[1].data_ptr(), wires[2].data_ptr(), gates, table, pi_pos,
                              pi_vals, blinders, tr)
 
+    from zkt_plonk_amd import parallel as par
+
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        par.barrier(dist)
         torch.cuda.synchronize(dev)
 
     proof = None
@@ -208,10 +209,7 @@ def main():
     prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "msm", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2),
                                             "ntt_pass", "quotient")}
     ctx.profile_enable(False)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = par.max_over_ranks(dist, elapsed, dev)   # whole-job time = slowest rank
     assert proof is not None and len(proof) == (802 if args.curve == "bn254" else 1010)
 
     total_proofs = args.steps * world

@@ -698,6 +698,14 @@ extern "C" int orc_params(int which, u64* out /* p, inv, r, r2 flattened */) {
     return 0;
 }
 
+extern "C" void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 extern "C" int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -54,7 +54,9 @@ def lib():
         L.orc_fq_convert.argtypes = [ctypes.c_int, ctypes.c_int, u64p, ctypes.c_size_t, u64p]
         L.orc_params.argtypes = [ctypes.c_int, u64p]
         L.orc_num_threads.restype = ctypes.c_int
-        _lib = L
+        L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_set_threads(int(os.environ.get("ORACLE_THREADS", _cpu_share())))  # env vars are read too late once
+        _lib = L                                                               # another OpenMP user is loaded
     return _lib
 
 

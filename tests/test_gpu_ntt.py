@@ -64,7 +64,10 @@ def test_ntt_matches_oracle_every_size(cv, log_n, ctxs):
     rng = np.random.default_rng(1000 + log_n)
     n = 1 << log_n
     # ragged input (zero padded by the transform) and full input
-    for in_len in sorted({n, max(1, n - 3), max(1, n // 4 + 3) if n >= 4 else n}):
+    lens = sorted({n, max(1, n - 3), max(1, n // 4 + 3) if n >= 4 else n})
+    if log_n >= 17:
+        lens = [n // 4 + 3]   # the prover's shape: <= n/4 + 3 coefficients on the 4x domain
+    for in_len in lens:
         x = rand_fr(rng, in_len)
         for name, inv, cos in VARIANTS:
             got = ctxs[cv.name].ntt(log_n, x, inverse=bool(inv), coset=bool(cos))
