@@ -187,6 +187,11 @@ int zkt_prove_with(zkt_ctx* ctx, const zkt_prove_inputs* in, const zkt_transcrip
 /* Dumps the compiled-in parameter tables (modulus, -p^-1 mod 2^32, R, R^2) as u32 words for
  * which = 0 (Fr) or 1 (Fq) of the context's curve; returns the limb count. */
 int zkt_debug_params(zkt_ctx* ctx, int which, uint32_t* out, size_t out_words);
+/* Runs a field routine on the HOST (the same __host__ __device__ code the kernels execute) so that
+ * the arithmetic can be pinned against big integers without a GPU.  which: 0 = Fr, 1 = Fq; a, b, out:
+ * packed Montgomery words (8 or 12 x u32).  op 0: product; 1: 32-bit-limb reference product;
+ * 2: arkworks form -> 29-bit limbs -> arkworks form; 3: 3*(a^2 - b^2) through the lazy add/sub/mul path. */
+int zkt_host_field_op(int curve_id, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
 /* Elementwise Fr product on the device (out[i] = a[i]*b[i], Montgomery); test hook for the field
  * kernels. Host pointers. */
 int zkt_debug_fr_mul(zkt_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);

@@ -245,6 +245,45 @@ int zkt_debug_params(zkt_ctx* c, int which, uint32_t* out, size_t out_words) {
     return which == 0 ? dump_params<Bls381Fr>(out, out_words) : dump_params<Bls381Fq>(out, out_words);
 }
 
+}  // extern "C"
+
+// Host-side execution of the field routines (same __host__ __device__ code the kernels run): lets the
+// CPU test-suite pin the 29-bit-limb arithmetic against big integers without a GPU.
+//   op 0: packed Montgomery product (fe_mul)          op 1: 32-bit-limb CIOS reference (fe_mul_sat)
+//   op 2: ark -> R'-limbs -> ark round trip           op 3: lazy chain  (a + b) * (a + 8p - b) reduced
+template <class P>
+static void host_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    Fe<P> x, y, r;
+    memcpy(x.v, a, P::N * 4);
+    memcpy(y.v, b, P::N * 4);
+    if (op == 0) {
+        r = fe_mul<P>(x, y);
+    } else if (op == 1) {
+        r = fe_mul_sat<P>(x, y);
+    } else if (op == 2) {
+        r = fx_to_ark<P>(fx_from_ark<P>(x));
+    } else {
+        Fx<P> xa = fx_from_ark<P>(x), ya = fx_from_ark<P>(y);
+        Fx<P> s = fx_add<P>(xa, ya);              // < 4p
+        Fx<P> d = fx_sub<P, 8>(xa, ya);           // < 10p
+        Fx<P> m = fx_mul<P>(s, d);                // (a+b)(a-b) in R' form, < 2p
+        r = fx_to_ark<P>(fx_add<P>(fx_add<P>(m, m), m));  // 3 (a^2 - b^2), lazily < 6p
+    }
+    memcpy(out, r.v, P::N * 4);
+}
+
+extern "C" {
+
+int zkt_host_field_op(int curve_id, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    if (!a || !b || !out) return ZKT_ERR_INVALID_ARGUMENT;
+    if (curve_id == ZKT_CURVE_BN254) {
+        if (which == 0) host_field_op<Bn254Fr>(op, a, b, out); else host_field_op<Bn254Fq>(op, a, b, out);
+    } else {
+        if (which == 0) host_field_op<Bls381Fr>(op, a, b, out); else host_field_op<Bls381Fq>(op, a, b, out);
+    }
+    return ZKT_OK;
+}
+
 int zkt_debug_fr_mul(zkt_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     if (!c || !a || !b || !out) return ZKT_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);

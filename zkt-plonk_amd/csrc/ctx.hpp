@@ -11,6 +11,7 @@
 
 #include "../../include/zkt_plonk.h"
 #include "fp.hpp"
+#include "fx.hpp"
 #include "ntt.hpp"
 
 namespace zkt {

@@ -8,6 +8,7 @@
 // resulting group element, hence the affine output, is identical.
 #pragma once
 #include "fp.hpp"
+#include "fx.hpp"
 
 namespace zkt {
 

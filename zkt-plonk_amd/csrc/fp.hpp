@@ -215,10 +215,16 @@ ZKT_HD Fe<P> fe_dbl(const Fe<P>& a) {
     return fe_add<P>(a, a);
 }
 
+// arkworks-form Montgomery product a*b*R^-1 mod p on packed operands; defined in fx.hpp.
+template <class P>
+__host__ __device__ Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b);
+
 // Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.  With >= 1 spare bit in the modulus
 // the running value stays < 2p, i.e. inside N+1 words, so no (N+2)-th word is carried.
+// (kept as the plain 32-bit-limb CIOS reference; the product every kernel uses is fe_mul below,
+// implemented on 29-bit limbs in fx.hpp)
 template <class P>
-ZKT_MUL Fe<P> fe_mul(Fe<P> a, Fe<P> b) {
+ZKT_MUL Fe<P> fe_mul_sat(Fe<P> a, Fe<P> b) {
     constexpr int N = P::N;
     uint32_t t[N + 1];
 #pragma unroll

@@ -1,0 +1,404 @@
+// Carry-free ("unsaturated") field arithmetic for gfx950: 29-bit limbs in 32-bit registers.
+//
+// Why: on MI355X v_mad_u64_u32 issues every ~4.4 cycles per wave but every carry-propagating
+// companion (v_add_co/v_addc 4.3, v_lshl_add_u64 4.2, plus the v_mov pairs the 64-bit operands
+// need) costs as much again (profiles/microbench_r01.txt).  With 29-bit limbs a 64-bit accumulator
+// absorbs all 2L partial products of a column without overflow, so the Montgomery product is
+// 2L^2 + L multiply-adds and nothing else in its inner loops; additions are L independent
+// full-rate adds.  L = 9 limbs (261 bits) for the 254/255-bit fields, 14 (406 bits) for Fq381.
+//
+// Representation: value = sum l[i] * 2^(29 i).  "Normalised": l[i] < 2^29 for i < L-1 (the top
+// limb keeps the excess).  Values are lazily reduced: every function states the bound it needs
+// and the bound it returns, in multiples of p.  Montgomery radix R' = 2^(29 L) = R * 2^SH where
+// R = 2^(32 N) is arkworks' radix; fx_unpack_shift() multiplies by 2^SH for free while unpacking,
+// which makes fx_mul(unpack(a~), unpack_shift(b~)) return (ab)~ in arkworks' own Montgomery form.
+#pragma once
+#include "fp.hpp"
+
+namespace zkt {
+
+// ---- compile-time big-number helpers (32-bit words, little endian) ---------------------------
+template <int N>
+struct Words {
+    uint32_t w[N];
+};
+
+template <int N>
+constexpr bool words_geq(const Words<N>& a, const Words<N>& b) {
+    for (int i = N - 1; i >= 0; --i) {
+        if (a.w[i] > b.w[i]) return true;
+        if (a.w[i] < b.w[i]) return false;
+    }
+    return true;
+}
+template <int N>
+constexpr Words<N> words_sub(const Words<N>& a, const Words<N>& b) {
+    Words<N> r{};
+    uint64_t borrow = 0;
+    for (int i = 0; i < N; ++i) {
+        uint64_t x = (uint64_t)a.w[i] - b.w[i] - borrow;
+        r.w[i] = (uint32_t)x;
+        borrow = (x >> 63) & 1;
+    }
+    return r;
+}
+// (2 * a) mod p for a < p, with one spare word so that the doubling cannot overflow
+template <int N>
+constexpr Words<N> words_dbl_mod(const Words<N>& a, const Words<N>& p) {
+    Words<N> r{};
+    uint32_t carry = 0;
+    for (int i = 0; i < N; ++i) {
+        r.w[i] = (a.w[i] << 1) | carry;
+        carry = a.w[i] >> 31;
+    }
+    // every modulus here has >= 1 spare bit, so 2a < 2^(32N)
+    if (words_geq<N>(r, p)) r = words_sub<N>(r, p);
+    return r;
+}
+template <class P>
+constexpr Words<P::N> words_modulus() {
+    Words<P::N> m{};
+    for (int i = 0; i < P::N; ++i) m.w[i] = P::mod(i);
+    return m;
+}
+// 2^k mod p as a canonical integer
+template <class P>
+constexpr Words<P::N> pow2_mod(int k) {
+    Words<P::N> p = words_modulus<P>();
+    Words<P::N> r{};
+    r.w[0] = 1;
+    for (int i = 0; i < k; ++i) r = words_dbl_mod<P::N>(r, p);
+    return r;
+}
+
+// ---- derived parameters -----------------------------------------------------------------------
+template <class P>
+struct FxP {
+    static constexpr int N = P::N;                       // 32-bit words of the packed form
+    static constexpr int L = (32 * P::N + 28) / 29;      // 29-bit limbs: 9 (N = 8), 14 (N = 12)
+    static constexpr int SH = 29 * L - 32 * P::N;        // R' = R * 2^SH : 5, 22
+    static constexpr uint32_t MASK = (1u << 29) - 1u;
+    static constexpr uint32_t INV = P::INV & MASK;       // -p^-1 mod 2^29
+
+    // limb i of a canonical integer given as 32-bit words
+    ZKT_HD static constexpr uint32_t limb_of(const Words<P::N>& x, int i) {
+        int lo = 29 * i;
+        int w = lo >> 5, o = lo & 31;
+        uint64_t v = 0;
+        if (w < P::N) v = x.w[w];
+        if (w + 1 < P::N) v |= (uint64_t)x.w[w + 1] << 32;
+        return (uint32_t)(v >> o) & MASK;
+    }
+    ZKT_HD static constexpr uint32_t mod(int i) {
+        constexpr Words<P::N> m = words_modulus<P>();
+        return limb_of(m, i);
+    }
+    // R' mod p (the Montgomery one of this representation), limb i
+    ZKT_HD static constexpr uint32_t one(int i) {
+        constexpr Words<P::N> v = pow2_mod<P>(29 * L);
+        return limb_of(v, i);
+    }
+    // 2^(32N) mod p = R mod p: fx_mul(x^, this) takes R'-Montgomery x^ to arkworks' R-Montgomery x~
+    ZKT_HD static constexpr uint32_t to_ark(int i) {
+        constexpr Words<P::N> v = pow2_mod<P>(32 * P::N);
+        return limb_of(v, i);
+    }
+    // 2^(2*29L - 32N) mod p: fx_mul(x~, this) takes arkworks' x~ to x^
+    ZKT_HD static constexpr uint32_t from_ark(int i) {
+        constexpr Words<P::N> v = pow2_mod<P>(2 * 29 * L - 32 * P::N);
+        return limb_of(v, i);
+    }
+    // limb i of K * p in normalised form (top limb keeps the excess); K <= 64
+    ZKT_HD static constexpr uint32_t kmod(int K, int i) {
+        uint64_t c = 0;
+        uint32_t out = 0;
+        for (int j = 0; j <= i; ++j) {
+            uint64_t x = (uint64_t)K * mod(j) + c;
+            out = (j == L - 1) ? (uint32_t)x : ((uint32_t)x & MASK);
+            c = x >> 29;
+        }
+        return out;
+    }
+    // window used to estimate value / p: bits [OFS, OFS + 32) ; p >> OFS has 24 significant bits
+    static constexpr int OFS = P::BITS - 24;
+    ZKT_HD static constexpr uint32_t pwin() {
+        constexpr Words<P::N> m = words_modulus<P>();
+        int w = OFS >> 5, o = OFS & 31;
+        uint64_t v = m.w[w];
+        if (w + 1 < P::N) v |= (uint64_t)m.w[w + 1] << 32;
+        return (uint32_t)(v >> o);
+    }
+    // floor(2^(32+20) / (pwin + 1)): q = (vwin * QM) >> 52 never overestimates value / p
+    ZKT_HD static constexpr uint32_t qm() { return (uint32_t)(((uint64_t)1 << 52) / ((uint64_t)pwin() + 1)); }
+};
+
+template <class P>
+struct Fx {
+    uint32_t l[FxP<P>::L];
+};
+
+template <class P>
+ZKT_HD Fx<P> fx_zero() {
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = 0;
+    return r;
+}
+template <class P>
+ZKT_HD Fx<P> fx_one() {  // R' mod p
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = FxP<P>::one(i);
+    return r;
+}
+template <class P>
+ZKT_HD Fx<P> fx_const_to_ark() {
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = FxP<P>::to_ark(i);
+    return r;
+}
+template <class P>
+ZKT_HD Fx<P> fx_const_from_ark() {
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = FxP<P>::from_ark(i);
+    return r;
+}
+
+// ---- packed (8 / 12 x u32) <-> limbs ---------------------------------------------------------------
+// value(a) * 2^S, S in {0, SH}: limb i = bits [29 i - S, 29 i - S + 29) of a.  Output normalised, < 2^S * a.
+template <class P, int S>
+ZKT_HD Fx<P> fx_unpack_s(const Fe<P>& a) {
+    constexpr int L = FxP<P>::L, N = P::N;
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int lo = 29 * i - S;  // may be negative for i = 0
+        uint32_t v;
+        if (lo < 0) {
+            v = a.v[0] << (-lo);
+        } else {
+            const int w = lo >> 5, o = lo & 31;
+            uint32_t x0 = (w < N) ? a.v[w] : 0u;
+            uint32_t x1 = (w + 1 < N) ? a.v[w + 1] : 0u;
+            v = o ? ((x0 >> o) | (x1 << (32 - o))) : x0;
+        }
+        r.l[i] = v & FxP<P>::MASK;  // nothing lives above bit 29 L - 1 either
+    }
+    return r;
+}
+template <class P>
+ZKT_HD Fx<P> fx_unpack(const Fe<P>& a) { return fx_unpack_s<P, 0>(a); }
+template <class P>
+ZKT_HD Fx<P> fx_unpack_shift(const Fe<P>& a) { return fx_unpack_s<P, FxP<P>::SH>(a); }
+
+// normalised limbs of a value < 2^(32N) -> packed words
+template <class P>
+ZKT_HD Fe<P> fx_pack(const Fx<P>& a) {
+    constexpr int L = FxP<P>::L, N = P::N;
+    Fe<P> r;
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+        const int lo = 32 * w;
+        const int i = lo / 29, o = lo - 29 * i;   // word w starts at bit o of limb i
+        uint32_t v = a.l[i] >> o;                  // 29 - o bits
+        if (i + 1 < L) v |= a.l[i + 1] << (29 - o);
+        if (29 - o + 29 < 32 && i + 2 < L) v |= a.l[i + 2] << (58 - o);
+        r.v[w] = v;
+    }
+    return r;
+}
+
+// ---- carries ---------------------------------------------------------------------------------------
+// limbs may hold up to 32 bits; afterwards l[i] < 2^29 for i < L-1.  Value unchanged.
+template <class P>
+ZKT_HD Fx<P> fx_normalize(const Fx<P>& a) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        uint32_t x = a.l[i] + c;   // callers keep limbs < 2^32 - 2^4
+        r.l[i] = x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    r.l[L - 1] = a.l[L - 1] + c;
+    return r;
+}
+
+// a + b, limbwise; result normalised, value = a + b (must stay < 2^(29 L))
+template <class P>
+ZKT_HD Fx<P> fx_add(const Fx<P>& a, const Fx<P>& b) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        uint32_t x = a.l[i] + b.l[i] + c;
+        r.l[i] = x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    r.l[L - 1] = a.l[L - 1] + b.l[L - 1] + c;
+    return r;
+}
+
+// a + K p - b, needs b <= K p (as values); result normalised, value < a + K p
+template <class P, int K>
+ZKT_HD Fx<P> fx_sub(const Fx<P>& a, const Fx<P>& b) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        // a.l, b.l < 2^29 (+ small), kmod < 2^29: everything fits a signed 32-bit limb
+        int32_t x = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)FxP<P>::kmod(K, i) + c;
+        r.l[i] = (uint32_t)x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    int32_t x = (int32_t)a.l[L - 1] - (int32_t)b.l[L - 1] + (int32_t)FxP<P>::kmod(K, L - 1) + c;
+    r.l[L - 1] = (uint32_t)x;
+    return r;
+}
+
+template <class P>
+ZKT_HD Fx<P> fx_dbl(const Fx<P>& a) { return fx_add<P>(a, a); }
+
+// ---- Montgomery product ------------------------------------------------------------------------------
+// a * b / R' mod p.  Needs normalised limbs (a.l, b.l < 2^29, top limb free) and a * b < R' * p as values
+// (e.g. a < 8p, b < 8p).  Returns normalised limbs, value < 2p.
+// The body is a real (non-inlined) function so that one copy stays hot in the instruction cache; its
+// operands travel as L-element vectors because a 9-word struct would be returned through scratch memory.
+template <class P>
+struct FxVec {
+    typedef uint32_t type __attribute__((ext_vector_type(FxP<P>::L)));
+};
+
+template <class P>
+ZKT_MUL typename FxVec<P>::type fx_mul_raw(typename FxVec<P>::type a, typename FxVec<P>::type b) {
+    constexpr int L = FxP<P>::L;
+    uint64_t t[L + 1];
+#pragma unroll
+    for (int j = 0; j <= L; ++j) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) t[j] += (uint64_t)a[j] * b[i];
+        const uint32_t m = ((uint32_t)t[0] * FxP<P>::INV) & FxP<P>::MASK;
+#pragma unroll
+        for (int j = 0; j < L; ++j) t[j] += (uint64_t)m * FxP<P>::mod(j);
+        const uint64_t carry = t[0] >> 29;  // low 29 bits are zero now
+#pragma unroll
+        for (int j = 0; j < L; ++j) t[j] = t[j + 1];
+        t[0] += carry;
+        t[L] = 0;
+    }
+    typename FxVec<P>::type r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < L - 1; ++j) {
+        uint64_t x = t[j] + c;
+        r[j] = (uint32_t)x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    r[L - 1] = (uint32_t)(t[L - 1] + c);
+    return r;
+}
+
+template <class P>
+ZKT_HD Fx<P> fx_mul(const Fx<P>& a, const Fx<P>& b) {
+    constexpr int L = FxP<P>::L;
+    typename FxVec<P>::type va, vb;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        va[i] = a.l[i];
+        vb[i] = b.l[i];
+    }
+    typename FxVec<P>::type vr = fx_mul_raw<P>(va, vb);
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.l[i] = vr[i];
+    return r;
+}
+template <class P>
+ZKT_HD Fx<P> fx_sqr(const Fx<P>& a) { return fx_mul<P>(a, a); }
+
+// value < 2^6 p (normalised) -> value' = value - q p in [0, 2p), same residue
+template <class P>
+ZKT_HD Fx<P> fx_reduce_small(const Fx<P>& a) {
+    constexpr int L = FxP<P>::L;
+    constexpr int OFS = FxP<P>::OFS;
+    constexpr int i0 = OFS / 29, o = OFS - 29 * i0;
+    // 32-bit window of the value starting at bit OFS (value < 2^(BITS + 6) -> window < 2^30)
+    uint64_t win = (uint64_t)a.l[i0] >> o;
+    if (i0 + 1 < L) win |= (uint64_t)a.l[i0 + 1] << (29 - o);
+    if (i0 + 2 < L) win |= (uint64_t)a.l[i0 + 2] << (58 - o);
+    const uint32_t q = (uint32_t)(((uint64_t)(uint32_t)win * FxP<P>::qm()) >> 52);
+    Fx<P> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        int64_t x = (int64_t)a.l[i] - (int64_t)((uint64_t)q * FxP<P>::mod(i)) + c;
+        r.l[i] = (uint32_t)x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    int64_t x = (int64_t)a.l[L - 1] - (int64_t)((uint64_t)q * FxP<P>::mod(L - 1)) + c;
+    r.l[L - 1] = (uint32_t)x;
+    return r;
+}
+
+// value < 2p (normalised) -> canonical [0, p)
+template <class P>
+ZKT_HD Fx<P> fx_cond_sub_p(const Fx<P>& a) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> d;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        int32_t x = (int32_t)a.l[i] - (int32_t)FxP<P>::mod(i) + c;
+        d.l[i] = (uint32_t)x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    int32_t top = (int32_t)a.l[L - 1] - (int32_t)FxP<P>::mod(L - 1) + c;
+    d.l[L - 1] = (uint32_t)top;
+    const bool neg = top < 0;
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.l[i] = neg ? a.l[i] : d.l[i];
+    return r;
+}
+// value < 2^6 p -> canonical
+template <class P>
+ZKT_HD Fx<P> fx_canon(const Fx<P>& a) { return fx_cond_sub_p<P>(fx_reduce_small<P>(a)); }
+
+template <class P>
+ZKT_HD bool fx_is_zero_canon(const Fx<P>& a) {  // a canonical
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) o |= a.l[i];
+    return o == 0;
+}
+
+// ---- arkworks-form product on packed operands: the drop-in behind fe_mul ---------------------------
+// a~ * b~ -> (ab)~, all canonical packed, R = 2^(32N) Montgomery form on both sides.
+template <class P>
+ZKT_HD Fe<P> fe_mul_via_fx(const Fe<P>& a, const Fe<P>& b) {
+    Fx<P> r = fx_mul<P>(fx_unpack<P>(a), fx_unpack_shift<P>(b));  // < p * 2^SH * p / R' + p < 2p
+    return fx_pack<P>(fx_cond_sub_p<P>(r));
+}
+template <class P>
+__host__ __device__ __forceinline__ Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    return fe_mul_via_fx<P>(a, b);
+}
+
+// arkworks packed (R form, canonical) <-> R'-Montgomery limbs
+template <class P>
+ZKT_HD Fx<P> fx_from_ark(const Fe<P>& a) {  // x~ -> x^ (< 2p)
+    return fx_mul<P>(fx_unpack<P>(a), fx_const_from_ark<P>());
+}
+template <class P>
+ZKT_HD Fe<P> fx_to_ark(const Fx<P>& a) {    // x^ (< 8p) -> canonical packed x~
+    return fx_pack<P>(fx_cond_sub_p<P>(fx_mul<P>(a, fx_const_to_ark<P>())));
+}
+
+}  // namespace zkt
