@@ -1,0 +1,196 @@
+// G1 arithmetic on lazily reduced 29-bit-limb field elements (fx.hpp), XYZZ coordinates.
+// Used by the MSM kernels; coordinates are in R' = 2^(29 L) Montgomery form throughout (the window
+// table is converted once at load time, the single result once at the end).
+//
+// Value bounds carried by an XyzzX between operations (p = base-field modulus):
+//     X < 8p,  Y < 4p,  ZZ < 2p,  ZZZ < 2p,   all limbs normalised.
+// Every product below satisfies a*b < 128 p^2 <= R' * p (BN254 Fq: R'/p ~ 168; BLS12-381 Fq: 2^25).
+#pragma once
+#include "ec.hpp"
+#include "fx.hpp"
+
+namespace zkt {
+
+template <class Q>
+struct AffineX {      // canonical coordinates (< p), R' form
+    Fx<Q> x, y;
+};
+template <class Q>
+struct XyzzX {
+    Fx<Q> x, y, zz, zzz;
+    bool inf;         // identity flag kept beside the lazily reduced coordinates
+};
+
+template <class Q>
+ZKT_HD XyzzX<Q> xx_identity() {
+    XyzzX<Q> r;
+    r.x = fx_zero<Q>();
+    r.y = fx_zero<Q>();
+    r.zz = fx_zero<Q>();
+    r.zzz = fx_zero<Q>();
+    r.inf = true;
+    return r;
+}
+
+// zero test for a product output (value < 2p, normalised): 0 or p
+template <class Q>
+ZKT_HD bool fx_is_zero_lt2p(const Fx<Q>& a) {
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < FxP<Q>::L; ++i) {
+        z |= a.l[i];
+        e |= a.l[i] ^ FxP<Q>::mod(i);
+    }
+    return z == 0 || e == 0;
+}
+
+// mdbl-2008-s on a canonical affine point
+template <class Q>
+ZKT_HD XyzzX<Q> xx_double_affine(const AffineX<Q>& p) {
+    XyzzX<Q> r;
+    const Fx<Q> u = fx_dbl<Q>(p.y);                    // < 2p
+    const Fx<Q> v = fx_sqr<Q>(u);
+    const Fx<Q> w = fx_mul<Q>(u, v);
+    const Fx<Q> s = fx_mul<Q>(p.x, v);
+    const Fx<Q> xx = fx_sqr<Q>(p.x);
+    const Fx<Q> m = fx_add<Q>(fx_dbl<Q>(xx), xx);      // < 6p
+    r.x = fx_sub<Q, 4>(fx_sqr<Q>(m), fx_dbl<Q>(s));    // < 6p
+    r.y = fx_sub<Q, 2>(fx_mul<Q>(m, fx_sub<Q, 8>(s, r.x)), fx_mul<Q>(w, p.y));  // < 4p
+    r.zz = v;
+    r.zzz = w;
+    r.inf = false;
+    return r;
+}
+
+// dbl-2008-s-1
+template <class Q>
+ZKT_HD XyzzX<Q> xx_double(const XyzzX<Q>& p) {
+    if (p.inf) return p;
+    XyzzX<Q> r;
+    const Fx<Q> u = fx_dbl<Q>(p.y);                    // < 8p
+    const Fx<Q> v = fx_sqr<Q>(u);                      // 64 p^2
+    const Fx<Q> w = fx_mul<Q>(u, v);
+    const Fx<Q> s = fx_mul<Q>(p.x, v);
+    const Fx<Q> xx = fx_sqr<Q>(p.x);                   // 64 p^2
+    const Fx<Q> m = fx_add<Q>(fx_dbl<Q>(xx), xx);      // < 6p
+    r.x = fx_sub<Q, 4>(fx_sqr<Q>(m), fx_dbl<Q>(s));    // < 6p
+    r.y = fx_sub<Q, 2>(fx_mul<Q>(m, fx_sub<Q, 8>(s, r.x)), fx_mul<Q>(w, p.y));  // 6p * 10p ; < 4p
+    r.zz = fx_mul<Q>(v, p.zz);
+    r.zzz = fx_mul<Q>(w, p.zzz);
+    r.inf = false;
+    return r;
+}
+
+// madd-2008-s; q canonical, not the point at infinity
+template <class Q>
+ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
+    if (p.inf) {
+        XyzzX<Q> r;
+        r.x = q.x;
+        r.y = q.y;
+        r.zz = fx_one<Q>();
+        r.zzz = fx_one<Q>();
+        r.inf = false;
+        return r;
+    }
+    const Fx<Q> u2 = fx_mul<Q>(q.x, p.zz);
+    const Fx<Q> s2 = fx_mul<Q>(q.y, p.zzz);
+    const Fx<Q> pp_ = fx_sub<Q, 8>(u2, p.x);           // < 10p
+    const Fx<Q> rr = fx_sub<Q, 4>(s2, p.y);            // < 6p
+    const Fx<Q> pp = fx_sqr<Q>(pp_);                   // 100 p^2
+    if (fx_is_zero_lt2p<Q>(pp)) {                      // same x: P == Q or P == -Q
+        if (fx_is_zero_lt2p<Q>(fx_sqr<Q>(rr))) return xx_double_affine<Q>(q);
+        return xx_identity<Q>();
+    }
+    const Fx<Q> ppp = fx_mul<Q>(pp_, pp);
+    const Fx<Q> qq = fx_mul<Q>(p.x, pp);
+    XyzzX<Q> r;
+    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(fx_sqr<Q>(rr), ppp), fx_dbl<Q>(qq));        // < 8p
+    r.y = fx_sub<Q, 2>(fx_mul<Q>(rr, fx_sub<Q, 8>(qq, r.x)), fx_mul<Q>(p.y, ppp));  // 6p * 10p ; < 4p
+    r.zz = fx_mul<Q>(p.zz, pp);
+    r.zzz = fx_mul<Q>(p.zzz, ppp);
+    r.inf = false;
+    return r;
+}
+
+// add-2008-s
+template <class Q>
+ZKT_HD XyzzX<Q> xx_add(const XyzzX<Q>& p, const XyzzX<Q>& q) {
+    if (p.inf) return q;
+    if (q.inf) return p;
+    const Fx<Q> u1 = fx_mul<Q>(p.x, q.zz);
+    const Fx<Q> u2 = fx_mul<Q>(q.x, p.zz);
+    const Fx<Q> s1 = fx_mul<Q>(p.y, q.zzz);
+    const Fx<Q> s2 = fx_mul<Q>(q.y, p.zzz);
+    const Fx<Q> pp_ = fx_sub<Q, 2>(u2, u1);            // < 4p
+    const Fx<Q> rr = fx_sub<Q, 2>(s2, s1);             // < 4p
+    const Fx<Q> pp = fx_sqr<Q>(pp_);
+    if (fx_is_zero_lt2p<Q>(pp)) {
+        if (fx_is_zero_lt2p<Q>(fx_sqr<Q>(rr))) return xx_double<Q>(p);
+        return xx_identity<Q>();
+    }
+    const Fx<Q> ppp = fx_mul<Q>(pp_, pp);
+    const Fx<Q> qq = fx_mul<Q>(u1, pp);
+    XyzzX<Q> r;
+    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(fx_sqr<Q>(rr), ppp), fx_dbl<Q>(qq));        // < 8p
+    r.y = fx_sub<Q, 2>(fx_mul<Q>(rr, fx_sub<Q, 8>(qq, r.x)), fx_mul<Q>(s1, ppp));  // < 4p
+    r.zz = fx_mul<Q>(fx_mul<Q>(p.zz, q.zz), pp);
+    r.zzz = fx_mul<Q>(fx_mul<Q>(p.zzz, q.zzz), ppp);
+    r.inf = false;
+    return r;
+}
+
+// ---- memory forms: canonical packed words (Fe containers), R' Montgomery form ----------------------
+template <class Q>
+ZKT_D AffineX<Q> affx_load(const Affine<Q>* p, bool* is_inf) {
+    const Fe<Q> x = fe_load<Q>(&p->x), y = fe_load<Q>(&p->y);
+    *is_inf = fe_is_zero<Q>(x) && fe_is_zero<Q>(y);
+    AffineX<Q> r;
+    r.x = fx_unpack<Q>(x);
+    r.y = fx_unpack<Q>(y);
+    return r;
+}
+template <class Q>
+ZKT_D XyzzX<Q> xx_load(const Xyzz<Q>* p) {
+    XyzzX<Q> r;
+    const Fe<Q> zz = fe_load<Q>(&p->zz);
+    r.inf = fe_is_zero<Q>(zz);
+    r.x = fx_unpack<Q>(fe_load<Q>(&p->x));
+    r.y = fx_unpack<Q>(fe_load<Q>(&p->y));
+    r.zz = fx_unpack<Q>(zz);
+    r.zzz = fx_unpack<Q>(fe_load<Q>(&p->zzz));
+    return r;
+}
+template <class Q>
+ZKT_D void xx_store(Xyzz<Q>* p, const XyzzX<Q>& a) {
+    if (a.inf) {
+        const Fe<Q> z = fe_zero<Q>();
+        fe_store<Q>(&p->x, z);
+        fe_store<Q>(&p->y, z);
+        fe_store<Q>(&p->zz, z);
+        fe_store<Q>(&p->zzz, z);
+        return;
+    }
+    fe_store<Q>(&p->x, fx_pack<Q>(fx_canon<Q>(a.x)));
+    fe_store<Q>(&p->y, fx_pack<Q>(fx_canon<Q>(a.y)));
+    fe_store<Q>(&p->zz, fx_pack<Q>(fx_canon<Q>(a.zz)));
+    fe_store<Q>(&p->zzz, fx_pack<Q>(fx_canon<Q>(a.zzz)));
+}
+// R' form -> arkworks R form (canonical packed), for the one point that leaves the MSM
+template <class Q>
+ZKT_D void xx_store_ark(Xyzz<Q>* p, const XyzzX<Q>& a) {
+    if (a.inf) {
+        const Fe<Q> z = fe_zero<Q>();
+        fe_store<Q>(&p->x, z);
+        fe_store<Q>(&p->y, z);
+        fe_store<Q>(&p->zz, z);
+        fe_store<Q>(&p->zzz, z);
+        return;
+    }
+    fe_store<Q>(&p->x, fx_to_ark<Q>(a.x));
+    fe_store<Q>(&p->y, fx_to_ark<Q>(a.y));
+    fe_store<Q>(&p->zz, fx_to_ark<Q>(a.zz));
+    fe_store<Q>(&p->zzz, fx_to_ark<Q>(a.zzz));
+}
+
+}  // namespace zkt

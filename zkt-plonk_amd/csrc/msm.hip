@@ -18,6 +18,7 @@
 //    coordinates for the Fiat-Shamir transcript anyway.
 #include "ctx.hpp"
 #include "ec.hpp"
+#include "ecx.hpp"
 
 #include <hipcub/hipcub.hpp>
 #include <cstring>
@@ -177,7 +178,9 @@ __global__ void k_msm_offsets(const uint32_t* keys, uint32_t m, uint32_t B, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// accumulation: fixed-size chunks over the sorted pairs, one piece per (chunk, bucket)
+// accumulation: fixed-size chunks over the sorted pairs, one piece per (chunk, bucket).
+// Coordinates live in registers as lazily reduced 29-bit limbs (ecx.hpp); table, pieces and buckets
+// are canonical packed words in R' Montgomery form.
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t m,
@@ -191,29 +194,32 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, co
     if (p0 >= m) return;
     const uint32_t p1 = (uint32_t)((p0 + MSM_CHUNK < m) ? p0 + MSM_CHUNK : m);
     uint32_t cur = keys[p0];
-    Xyzz<Q> acc = xyzz_identity<Q>();
+    XyzzX<Q> acc = xx_identity<Q>();
     uint32_t v = vals[p0];
-    Affine<Q> pt = aff_load<Q>(table + (v & 0x7fffffffu));
+    Fe<Q> nx = fe_load<Q>(&table[v & 0x7fffffffu].x), ny = fe_load<Q>(&table[v & 0x7fffffffu].y);
     for (uint32_t p = (uint32_t)p0; p < p1; ++p) {
         const uint32_t key = keys[p];
         const uint32_t vcur = v;
-        const Affine<Q> pcur = pt;
+        const Fe<Q> cx = nx, cy = ny;
         if (p + 1 < p1) {  // prefetch the next gathered point behind this addition
             v = vals[p + 1];
-            pt = aff_load<Q>(table + (v & 0x7fffffffu));
+            nx = fe_load<Q>(&table[v & 0x7fffffffu].x);
+            ny = fe_load<Q>(&table[v & 0x7fffffffu].y);
         }
         if (key != cur) {
-            xyzz_store<Q>(pieces + (size_t)t + cur, acc);
-            acc = xyzz_identity<Q>();
+            xx_store<Q>(pieces + (size_t)t + cur, acc);
+            acc = xx_identity<Q>();
             cur = key;
         }
-        if (!aff_is_inf<Q>(pcur)) {
-            Affine<Q> q = pcur;
-            if (vcur >> 31) q.y = fe_neg<Q>(q.y);
-            acc = xyzz_add_mixed<Q>(acc, q);
+        if (!(fe_is_zero<Q>(cx) && fe_is_zero<Q>(cy))) {
+            AffineX<Q> q;
+            q.x = fx_unpack<Q>(cx);
+            q.y = fx_unpack<Q>(cy);
+            if (vcur >> 31) q.y = fx_sub<Q, 1>(fx_zero<Q>(), q.y);  // -y = p - y
+            acc = xx_add_mixed<Q>(acc, q);
         }
     }
-    xyzz_store<Q>(pieces + (size_t)t + cur, acc);
+    xx_store<Q>(pieces + (size_t)t + cur, acc);
 }
 
 template <class C>
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets,
     using Q = typename C::Fq;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..B ; bucket 0 is the identity
     if (b > B) return;
-    Xyzz<Q> acc = xyzz_identity<Q>();
+    XyzzX<Q> acc = xx_identity<Q>();
     if (b >= 1) {
         const uint32_t base = offsets[1];
         const uint32_t s = offsets[b], e = offsets[b + 1];
@@ -233,40 +239,46 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets,
                 heavy[1 + atomicAdd(heavy, 1u)] = b;
                 return;
             }
-            acc = xyzz_load<Q>(pieces + (size_t)t0 + b);
-            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xyzz_add<Q>(acc, xyzz_load<Q>(pieces + (size_t)t + b));
+            if (t1 == t0) {  // a single piece: plain copy
+                xyzz_store<Q>(buckets + b, xyzz_load<Q>(pieces + (size_t)t0 + b));
+                return;
+            }
+            acc = xx_load<Q>(pieces + (size_t)t0 + b);
+            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xx_add<Q>(acc, xx_load<Q>(pieces + (size_t)t + b));
         }
     }
-    xyzz_store<Q>(buckets + b, acc);
+    xx_store<Q>(buckets + b, acc);
 }
 
 template <class Q>
-ZKT_D Xyzz<Q> xyzz_shfl_down(const Xyzz<Q>& p, int delta) {
-    Xyzz<Q> r;
+ZKT_D XyzzX<Q> xx_shfl_down(const XyzzX<Q>& p, int delta) {
+    XyzzX<Q> r;
 #pragma unroll
-    for (int i = 0; i < Q::N; ++i) {
-        r.x.v[i] = __shfl_down(p.x.v[i], delta);
-        r.y.v[i] = __shfl_down(p.y.v[i], delta);
-        r.zz.v[i] = __shfl_down(p.zz.v[i], delta);
-        r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta);
+    for (int i = 0; i < FxP<Q>::L; ++i) {
+        r.x.l[i] = __shfl_down(p.x.l[i], delta);
+        r.y.l[i] = __shfl_down(p.y.l[i], delta);
+        r.zz.l[i] = __shfl_down(p.zz.l[i], delta);
+        r.zzz.l[i] = __shfl_down(p.zzz.l[i], delta);
     }
+    r.inf = __shfl_down((int)p.inf, delta) != 0;
     return r;
 }
 
-// block-wide sum of one XYZZ value per thread (256 threads); result valid in thread 0
+// block-wide sum of one point per thread (256 threads); result valid in thread 0.  `wsum`: 4 LDS slots.
 template <class Q>
-ZKT_D Xyzz<Q> block_sum_256(Xyzz<Q> acc, Xyzz<Q>* wsum /* 4 entries of LDS */) {
+ZKT_D XyzzX<Q> block_sum_256(XyzzX<Q> acc, Xyzz<Q>* wsum) {
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
-        Xyzz<Q> o = xyzz_shfl_down<Q>(acc, d);
-        acc = xyzz_add<Q>(acc, o);
+        XyzzX<Q> o = xx_shfl_down<Q>(acc, d);
+        if ((threadIdx.x & 63) + d >= 64) o = xx_identity<Q>();
+        acc = xx_add<Q>(acc, o);
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wsum[wv] = acc;
+    if (lane == 0) xx_store<Q>(wsum + wv, acc);
     __syncthreads();
     if (threadIdx.x == 0) {
-        acc = wsum[0];
-        for (int i = 1; i < 4; ++i) acc = xyzz_add<Q>(acc, wsum[i]);
+        acc = xx_load<Q>(wsum);
+        for (int i = 1; i < 4; ++i) acc = xx_add<Q>(acc, xx_load<Q>(wsum + i));
     }
     __syncthreads();
     return acc;
@@ -284,10 +296,10 @@ __global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, cons
         const uint32_t b = heavy[1 + h];
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
-        Xyzz<Q> acc = xyzz_identity<Q>();
-        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xyzz_add<Q>(acc, xyzz_load<Q>(pieces + (size_t)t + b));
+        XyzzX<Q> acc = xx_identity<Q>();
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xx_add<Q>(acc, xx_load<Q>(pieces + (size_t)t + b));
         acc = block_sum_256<Q>(acc, wsum);
-        if (threadIdx.x == 0) xyzz_store<Q>(buckets + b, acc);
+        if (threadIdx.x == 0) xx_store<Q>(buckets + b, acc);
     }
 }
 
@@ -302,15 +314,15 @@ __global__ __launch_bounds__(256) void k_msm_segments(const Xyzz<typename C::Fq>
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseg) return;
     const Xyzz<Q>* a = buckets + (size_t)s * MSM_SEG;
-    Xyzz<Q> run = xyzz_identity<Q>(), acc = xyzz_identity<Q>();
+    XyzzX<Q> run = xx_identity<Q>(), acc = xx_identity<Q>();
 #pragma unroll 1
     for (int j = MSM_SEG - 1; j >= 1; --j) {
-        run = xyzz_add<Q>(run, xyzz_load<Q>(a + j));
-        acc = xyzz_add<Q>(acc, run);
+        run = xx_add<Q>(run, xx_load<Q>(a + j));
+        acc = xx_add<Q>(acc, run);
     }
-    run = xyzz_add<Q>(run, xyzz_load<Q>(a));
-    xyzz_store<Q>(segA + s, acc);
-    xyzz_store<Q>(segT + s, run);
+    run = xx_add<Q>(run, xx_load<Q>(a));
+    xx_store<Q>(segA + s, acc);
+    xx_store<Q>(segT + s, run);
 }
 
 // y = 0: plain sum of segA ; y = k + 1: sum of segT[s] over s with bit k set.  One partial per block.
@@ -322,38 +334,53 @@ __global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::
     __shared__ Xyzz<Q> wsum[4];
     const int y = blockIdx.y;
     const Xyzz<Q>* src = (y == 0) ? segA : segT;
-    Xyzz<Q> acc = xyzz_identity<Q>();
+    XyzzX<Q> acc = xx_identity<Q>();
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
-        if (y == 0 || ((s >> (y - 1)) & 1u)) acc = xyzz_add<Q>(acc, xyzz_load<Q>(src + s));
+        if (y == 0 || ((s >> (y - 1)) & 1u)) acc = xx_add<Q>(acc, xx_load<Q>(src + s));
     }
     acc = block_sum_256<Q>(acc, wsum);
-    if (threadIdx.x == 0) xyzz_store<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
+    if (threadIdx.x == 0) xx_store<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
 }
 
-// result = sum_y 2^(e_y) * V_y ; V_y = sum of the y-th row of partials, plus the top bucket with e = c-1
+// result = sum_y 2^(e_y) * V_y ; V_y = sum of the y-th row of partials, plus the top bucket with e = c-1.
+// The result leaves in arkworks' R-Montgomery form.
 template <class C>
 __global__ __launch_bounds__(64) void k_msm_final(const Xyzz<typename C::Fq>* partials, int ny, int nblk,
                                                   const Xyzz<typename C::Fq>* top_bucket, int c,
                                                   Xyzz<typename C::Fq>* result) {
     using Q = typename C::Fq;
     const int y = threadIdx.x;
-    Xyzz<Q> v = xyzz_identity<Q>();
+    XyzzX<Q> v = xx_identity<Q>();
     int e = 0;
     if (y < ny) {
-        for (int j = 0; j < nblk; ++j) v = xyzz_add<Q>(v, xyzz_load<Q>(partials + (size_t)y * nblk + j));
+        for (int j = 0; j < nblk; ++j) v = xx_add<Q>(v, xx_load<Q>(partials + (size_t)y * nblk + j));
         e = (y == 0) ? 0 : (y - 1) + 3;  // SEG = 8 = 2^3
     } else if (y == ny) {
-        v = xyzz_load<Q>(top_bucket);
+        v = xx_load<Q>(top_bucket);
         e = c - 1;
     }
 #pragma unroll 1
-    for (int k = 0; k < e; ++k) v = xyzz_double<Q>(v);
+    for (int k = 0; k < e; ++k) v = xx_double<Q>(v);
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
-        Xyzz<Q> o = xyzz_shfl_down<Q>(v, d);
-        v = xyzz_add<Q>(v, o);
+        XyzzX<Q> o = xx_shfl_down<Q>(v, d);
+        if (y + d >= 64) o = xx_identity<Q>();
+        v = xx_add<Q>(v, o);
     }
-    if (y == 0) xyzz_store<Q>(result, v);
+    if (y == 0) xx_store_ark<Q>(result, v);
+}
+
+// table: arkworks R form -> R' form (canonical packed), in place; (0,0) stays (0,0)
+template <class C>
+__global__ void k_srs_to_fx(Affine<typename C::Fq>* table, size_t total) {
+    using Q = typename C::Fq;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Affine<Q> a = aff_load<Q>(table + i);
+    if (aff_is_inf<Q>(a)) return;
+    a.x = fx_pack<Q>(fx_cond_sub_p<Q>(fx_from_ark<Q>(a.x)));
+    a.y = fx_pack<Q>(fx_cond_sub_p<Q>(fx_from_ark<Q>(a.y)));
+    aff_store<Q>(table + i, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -425,6 +452,10 @@ static int srs_finish(zkt_ctx* c) {
     MsmState& st = *c->msm;
     unsigned blocks = (unsigned)((st.count + 127) / 128);
     hipLaunchKernelGGL(k_srs_windows<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)st.table, st.count, st.win);
+    ZKT_HIP(c, hipGetLastError());
+    const size_t total = (size_t)st.W * st.count;
+    hipLaunchKernelGGL(k_srs_to_fx<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       (Affine<Q>*)st.table, total);
     ZKT_HIP(c, hipGetLastError());
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
     return ZKT_OK;
@@ -591,6 +622,15 @@ int srs_generate(zkt_ctx* c, const uint64_t* tau4, size_t count) {
     if (c->curve == ZKT_CURVE_BN254) return srs_generate_t<Bn254Curve>(c, tau4, count);
     return srs_generate_t<Bls381Curve>(c, tau4, count);
 }
+template <class Q>
+static void table_to_ark(Affine<Q>* pts, size_t count) {
+    for (size_t i = 0; i < count; ++i) {
+        if (aff_is_inf<Q>(pts[i])) continue;
+        pts[i].x = fx_to_ark<Q>(fx_unpack<Q>(pts[i].x));
+        pts[i].y = fx_to_ark<Q>(fx_unpack<Q>(pts[i].y));
+    }
+}
+
 int srs_download(zkt_ctx* c, size_t offset, size_t count, uint64_t* out) {
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded");
     if (offset > c->msm->count || count > c->msm->count - offset) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "range");
@@ -598,6 +638,9 @@ int srs_download(zkt_ctx* c, size_t offset, size_t count, uint64_t* out) {
     ZKT_HIP(c, hipMemcpyAsync(out, (const char*)c->msm->table + offset * psz, count * psz, hipMemcpyDeviceToHost,
                               c->stream));
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    // the device table is kept in R' = 2^(29 L) Montgomery form; hand back arkworks' R form (test / bench aid)
+    if (c->curve == ZKT_CURVE_BN254) table_to_ark<Bn254Fq>((Affine<Bn254Fq>*)out, count);
+    else table_to_ark<Bls381Fq>((Affine<Bls381Fq>*)out, count);
     return ZKT_OK;
 }
 void msm_info(zkt_ctx* c, int* cbits, int* windows, size_t* count) {
