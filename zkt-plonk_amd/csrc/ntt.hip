@@ -8,54 +8,67 @@ constexpr int TILE = 1 << TILE_LOG;   // 1024 x 32 B = 32 KiB of LDS
 constexpr int NTT_THREADS = 128;      // 8 elements per thread
 constexpr int EPT = TILE / NTT_THREADS;
 
-// LDS tile as two 16-byte planes so that consecutive lanes touch consecutive 16-B slots
-// (ds_read_b128 / ds_write_b128 conflict-free for unit-stride columns).
+// LDS tile: every element is held as nine 29-bit limbs (fx.hpp), lazily reduced (< 2p between steps),
+// in three planes (limbs 0-3, 4-7, 8) so that consecutive lanes touch consecutive 16-byte / 4-byte slots.
 template <class P>
-ZKT_D Fe<P> lds_get(const uint4* lo, const uint4* hi, int idx) {
-    static_assert(P::N == 8, "scalar fields are 8 x u32");
-    uint4 a = lo[idx], b = hi[idx];
-    Fe<P> r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+ZKT_D Fx<P> tile_get(const uint4* lo, const uint4* hi, const uint32_t* top, int idx) {
+    static_assert(FxP<P>::L == 9, "scalar fields use nine limbs");
+    const uint4 a = lo[idx], b = hi[idx];
+    Fx<P> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = top[idx];
     return r;
 }
 template <class P>
-ZKT_D void lds_put(uint4* lo, uint4* hi, int idx, const Fe<P>& x) {
-    lo[idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    hi[idx] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+ZKT_D void tile_put(uint4* lo, uint4* hi, uint32_t* top, int idx, const Fx<P>& x) {
+    lo[idx] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    hi[idx] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    top[idx] = x.l[8];
 }
 
 ZKT_D uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
-// One radix-2^G DIF step on 2^G elements held in registers.
+// One radix-2^G DIF step on 2^G elements held in registers (inputs < 2p, limbs normalised).
 //   level L: block size m = R >> L; element i sits at row blk*m + i*sub + off, sub = m >> G.
-//   sub-level l pairs (i, i + h), h = 2^(G-1-l); twiddle W_R^((i & (h-1))*sub + off) << (L + l)).
-template <class P, int G>
-ZKT_D void dif_group(Fe<P>* x, const Fe<P>* w_inner, int off, int sub, int L) {
+//   sub-level l pairs (i, i + h), h = 2^(G-1-l); twiddle W_R^(((i & (h-1))*sub + off) << (L + l)).
+// Lazy bounds: at sub-level l the inputs are < 2^(l+1) p; sums double, differences get K = 2^(l+1)
+// multiples of p added and are brought back below 2p by the twiddle product (twiddles are canonical,
+// R'-Montgomery form, so the product needs no more than a * p < R' p).  In the LAST step of a pass
+// (sub == 1, off == 0) the twiddle index depends on i only: W^0 products are skipped at compile time.
+template <class P, int G, bool LASTSTEP>
+ZKT_D void dif_group(Fx<P>* x, const Fe<P>* w_inner, int off, int sub, int L) {
 #pragma unroll
     for (int l = 0; l < G; ++l) {
         const int h = 1 << (G - 1 - l);
 #pragma unroll
         for (int i = 0; i < (1 << G); ++i) {
             if ((i & h) == 0) {
-                Fe<P> u = x[i], v = x[i + h];
-                x[i] = fe_add<P>(u, v);
-                Fe<P> d = fe_sub<P>(u, v);
-                int e = ((i & (h - 1)) * sub + off) << (L + l);
-                // e == 0 only for the last level / first column: keep the multiply uniform
-                x[i + h] = fe_mul<P>(d, fe_load<P>(w_inner + e));
+                const Fx<P> u = x[i], v = x[i + h];
+                x[i] = fx_add<P>(u, v);
+                Fx<P> d;
+                if (l == 0) d = fx_sub<P, 2>(u, v);
+                else if (l == 1) d = fx_sub<P, 4>(u, v);
+                else d = fx_sub<P, 8>(u, v);
+                if (LASTSTEP && (i & (h - 1)) == 0) {
+                    x[i + h] = d;  // twiddle is W^0 = 1
+                } else {
+                    const int e = ((i & (h - 1)) * sub + off) << (L + l);
+                    x[i + h] = fx_mul<P>(d, fx_unpack<P>(fe_load<P>(w_inner + e)));
+                }
             }
         }
     }
 }
 
 template <class P, int LOG_R, int G, int L>
-ZKT_D void dif_step(uint4* lo, uint4* hi, const Fe<P>* w_inner, int tid) {
+ZKT_D void dif_step(uint4* lo, uint4* hi, uint32_t* top, const Fe<P>* w_inner, int tid) {
     constexpr int R = 1 << LOG_R;
     constexpr int T = TILE >> LOG_R;
     constexpr int m = R >> L;
     constexpr int sub = m >> G;
     constexpr int UNITS = EPT >> G;  // independent radix-2^G groups per thread
+    constexpr bool LASTSTEP = (L + G == LOG_R);
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
         int q = tid * UNITS + u;
@@ -64,40 +77,46 @@ ZKT_D void dif_step(uint4* lo, uint4* hi, const Fe<P>* w_inner, int tid) {
         int off = rest % sub;
         int blk = rest / sub;
         int row0 = blk * m + off;
-        Fe<P> x[1 << G];
+        Fx<P> x[1 << G];
 #pragma unroll
-        for (int i = 0; i < (1 << G); ++i) x[i] = lds_get<P>(lo, hi, (row0 + i * sub) * T + c);
-        dif_group<P, G>(x, w_inner, off, sub, L);
+        for (int i = 0; i < (1 << G); ++i) x[i] = tile_get<P>(lo, hi, top, (row0 + i * sub) * T + c);
+        dif_group<P, G, LASTSTEP>(x, w_inner, off, sub, L);
+        // values that did not end on a twiddle product may have grown to 2^(G+1) p: bring them below 2p
 #pragma unroll
-        for (int i = 0; i < (1 << G); ++i) lds_put<P>(lo, hi, (row0 + i * sub) * T + c, x[i]);
+        for (int i = 0; i < (1 << G); ++i) {
+            const bool grown = LASTSTEP || ((i & 1) == 0);
+            tile_put<P>(lo, hi, top, (row0 + i * sub) * T + c, grown ? fx_reduce_small<P>(x[i]) : x[i]);
+        }
     }
 }
 
 template <class P, int LOG_R>
-ZKT_D void dif_all(uint4* lo, uint4* hi, const Fe<P>* w, int tid) {
+ZKT_D void dif_all(uint4* lo, uint4* hi, uint32_t* top, const Fe<P>* w, int tid) {
     if constexpr (LOG_R == 5) {
-        dif_step<P, 5, 3, 0>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 5, 2, 3>(lo, hi, w, tid);
+        dif_step<P, 5, 3, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 5, 2, 3>(lo, hi, top, w, tid);
     } else if constexpr (LOG_R == 6) {
-        dif_step<P, 6, 3, 0>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 6, 3, 3>(lo, hi, w, tid);
+        dif_step<P, 6, 3, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 6, 3, 3>(lo, hi, top, w, tid);
     } else if constexpr (LOG_R == 7) {
-        dif_step<P, 7, 3, 0>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 7, 3, 3>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 7, 1, 6>(lo, hi, w, tid);
+        dif_step<P, 7, 3, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 7, 3, 3>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 7, 1, 6>(lo, hi, top, w, tid);
     } else if constexpr (LOG_R == 8) {
-        dif_step<P, 8, 3, 0>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 8, 3, 3>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 8, 2, 6>(lo, hi, w, tid);
+        dif_step<P, 8, 3, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 8, 3, 3>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 8, 2, 6>(lo, hi, top, w, tid);
     } else {
         static_assert(LOG_R == 9, "unsupported radix");
-        dif_step<P, 9, 3, 0>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 9, 3, 3>(lo, hi, w, tid); __syncthreads();
-        dif_step<P, 9, 3, 6>(lo, hi, w, tid);
+        dif_step<P, 9, 3, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 9, 3, 3>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 9, 3, 6>(lo, hi, top, w, tid);
     }
 }
 
 // One pass: R-point transforms of a [R][T] tile.  LAST selects the transposing pass.
+// Tables (w_inner, in_row, tw, out_row) are canonical packed words in R' = 2^261 Montgomery form, the data
+// stay in arkworks' R = 2^256 form: data * table / R' keeps the data's form.
 template <class P, int LOG_R, bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     constexpr int R = 1 << LOG_R;
@@ -105,6 +124,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     constexpr int T = 1 << LOG_T;
     __shared__ uint4 lds_lo[TILE];
     __shared__ uint4 lds_hi[TILE];
+    __shared__ uint32_t lds_top[TILE];
     __shared__ Fe<P> lds_w[R / 2];
 
     const int tid = threadIdx.x;
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     }
 
     // ---- load (coalesced along the contiguous axis), fused input scaling ----
-#pragma unroll
+#pragma unroll 2
     for (int e = 0; e < EPT; ++e) {
         int flat = e * NTT_THREADS + tid;
         int r, c;
@@ -159,30 +179,38 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
             c = flat >> LOG_R;
         }
         uint64_t g = in_base + (uint64_t)r * ld_r + (uint64_t)c * ld_c;
-        Fe<P> x = (g < a.in_len) ? fe_load<P>(in + g) : fe_zero<P>();
-        if (in_row) x = fe_mul<P>(x, fe_load<P>(in_row + r));
+        Fx<P> x = (g < a.in_len) ? fx_unpack<P>(fe_load<P>(in + g)) : fx_zero<P>();
+        if (in_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(in_row + r)));
         if (tw) {
             uint64_t ti = LAST ? (tw_base + ((uint64_t)c << LOG_R) + r) : (tw_base + r);
-            x = fe_mul<P>(x, fe_load<P>(tw + ti));
+            x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(tw + ti)));
         }
-        lds_put<P>(lds_lo, lds_hi, r * T + c, x);
+        tile_put<P>(lds_lo, lds_hi, lds_top, r * T + c, x);
     }
     __syncthreads();
 
-    dif_all<P, LOG_R>(lds_lo, lds_hi, lds_w, tid);
+    dif_all<P, LOG_R>(lds_lo, lds_hi, lds_top, lds_w, tid);
     __syncthreads();
 
-    // ---- store: row rho of the tile holds frequency bitrev(rho) ----
-#pragma unroll
+    // ---- store: row rho of the tile holds frequency bitrev(rho); canonicalise on the way out ----
+#pragma unroll 2
     for (int e = 0; e < EPT; ++e) {
         int flat = e * NTT_THREADS + tid;
         int c = flat & (T - 1);
         int k = flat >> LOG_T;
         int rho = (int)bitrev32((uint32_t)k, LOG_R);
-        Fe<P> x = lds_get<P>(lds_lo, lds_hi, rho * T + c);
-        if (out_row) x = fe_mul<P>(x, fe_load<P>(out_row + k));
-        fe_store<P>(out + out_base + (uint64_t)k * st_k + c, x);
+        Fx<P> x = tile_get<P>(lds_lo, lds_hi, lds_top, rho * T + c);
+        if (out_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(out_row + k)));
+        fe_store<P>(out + out_base + (uint64_t)k * st_k + c, fx_pack<P>(fx_cond_sub_p<P>(x)));
     }
+}
+
+// table entries: arkworks R form -> canonical R' form, in place (pass-kernel tables only)
+template <class P>
+__global__ void k_table_to_fx(Fe<P>* t, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store<P>(t + i, fx_pack<P>(fx_cond_sub_p<P>(fx_from_ark<P>(fe_load<P>(t + i)))));
 }
 
 // Whole transform in one workgroup for n <= 1024 (plumbing sizes; not a performance path).
@@ -315,6 +343,14 @@ static int gen_tw2d(zkt_ctx* c, void* out, uint64_t rows, uint32_t log_cols, con
 }
 
 template <class P>
+static int table_to_fx(zkt_ctx* c, void* t, uint64_t n) {
+    if (!t || !n) return ZKT_OK;
+    hipLaunchKernelGGL(k_table_to_fx<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (Fe<P>*)t, n);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+
+template <class P>
 static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>& pl) {
     pl.log_n = log_n;
     pl.inverse = inverse;
@@ -405,6 +441,18 @@ static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>&
         if ((rc = alloc_table(c, pl, &pl.out_row, (size_t)1 << pl.log_r[p - 1]))) return rc;
         if ((rc = gen_pow<P>(c, pl.out_row, (uint64_t)1 << pl.log_r[p - 1], gp, one))) return rc;
     }
+    // the pass kernels multiply lazily reduced 29-bit-limb data by these tables: keep them in R' form
+    for (int i = 0; i < p; ++i)
+        if ((rc = table_to_fx<P>(c, pl.w_inner[i], (uint64_t)1 << (pl.log_r[i] - 1)))) return rc;
+    if ((rc = table_to_fx<P>(c, pl.in_row, (uint64_t)1 << pl.log_r[0]))) return rc;
+    {
+        int acc2 = 0;
+        for (int i = 1; i < p; ++i) {
+            acc2 += pl.log_r[i - 1];
+            if ((rc = table_to_fx<P>(c, pl.tw[i], (uint64_t)1 << (acc2 + pl.log_r[i])))) return rc;
+        }
+    }
+    if ((rc = table_to_fx<P>(c, pl.out_row, (uint64_t)1 << pl.log_r[p - 1]))) return rc;
     return 0;
 }
 

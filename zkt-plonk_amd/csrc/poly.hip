@@ -24,9 +24,16 @@ __global__ void k_mul_vec(const Fe<P>* a, const Fe<P>* b, Fe<P>* o, size_t n) {
 // number of coefficients after stripping trailing zeros (DensePolynomial::from_coefficients_vec)
 template <class P>
 __global__ void k_trim_len(const Fe<P>* p, size_t n, uint32_t* len) {
+    // one atomic per wave (the polynomial is dense: a per-element atomicMax would serialise on one address)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (!fe_is_zero<P>(fe_load<P>(p + i))) atomicMax(len, (uint32_t)(i + 1));
+    uint32_t v = 0;
+    if (i < n && !fe_is_zero<P>(fe_load<P>(p + i))) v = (uint32_t)(i + 1);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_down(v, d);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(len, v);
 }
 
 // prove.rs:472-483: coeffs.extend(blinders); coeffs[i] -= blinder[i]
