@@ -54,21 +54,23 @@ static hipEvent_t prof_event(zkt_ctx* c) {
     (void)hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(zkt_ctx* ctx, const char* name) : c(ctx) {
+ProfScope::ProfScope(zkt_ctx* ctx, const char* name, hipStream_t on_stream) : c(ctx) {
     if (!c->prof_on) return;
+    stream = on_stream ? on_stream : c->stream;
     slot = &c->prof[name];
     e0 = prof_event(c);
     e1 = prof_event(c);
-    (void)hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, stream);
 }
 ProfScope::~ProfScope() {
     if (!slot) return;
-    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventRecord(e1, stream);
     slot->pending.emplace_back(e0, e1);
     slot->calls += 1;
 }
 static void prof_resolve(zkt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();  // scopes may have been recorded on the MSM side stream
     for (auto& kv : c->prof) {
         for (auto& pr : kv.second.pending) {
             float ms = 0.f;

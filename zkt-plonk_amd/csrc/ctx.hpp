@@ -70,7 +70,8 @@ struct ProfScope {
     zkt_ctx* c;
     zkt_ctx::ProfSlot* slot = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(zkt_ctx* ctx, const char* name);
+    hipStream_t stream = nullptr;
+    ProfScope(zkt_ctx* ctx, const char* name, hipStream_t on_stream = nullptr);
     ~ProfScope();
 };
 

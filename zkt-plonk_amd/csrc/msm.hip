@@ -55,14 +55,25 @@ struct MsmState {
     size_t cub_bytes = 0;
     uint32_t* offsets = nullptr;  // B + 2
     void* pieces = nullptr;       // Xyzz[max_chunks + B + 2]
-    void* buckets = nullptr;      // Xyzz[B + 1]
-    void* segA = nullptr;         // Xyzz[B / SEG]
-    void* segT = nullptr;
-    void* partials = nullptr;     // Xyzz[MAX_Y * R2_BLOCKS]
-    void* result = nullptr;       // Xyzz
-    void* host_result = nullptr;  // pinned
+    // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
+    // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
+    static constexpr int SLOTS = 3;
+    void* buckets[SLOTS] = {};      // Xyzz[B + 1]
+    void* segA[SLOTS] = {};         // Xyzz[B / SEG]
+    void* segT[SLOTS] = {};
+    void* partials[SLOTS] = {};     // Xyzz[MAX_Y * R2_BLOCKS]
+    void* result[SLOTS] = {};       // Xyzz
+    void* host_result[SLOTS] = {};  // pinned
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
+    bool pending[SLOTS] = {};
     ~MsmState() {
-        if (host_result) (void)hipHostFree(host_result);
+        for (int i = 0; i < SLOTS; ++i) {
+            if (host_result[i]) (void)hipHostFree(host_result[i]);
+            if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
+            if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+        }
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -435,13 +446,18 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
     size_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
     if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(Xyzz<Q>)))) return rc;
-    if ((rc = dev_alloc(c, &st->buckets, ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
     size_t nseg = st->B / MSM_SEG;
-    if ((rc = dev_alloc(c, &st->segA, nseg * sizeof(Xyzz<Q>)))) return rc;
-    if ((rc = dev_alloc(c, &st->segT, nseg * sizeof(Xyzz<Q>)))) return rc;
-    if ((rc = dev_alloc(c, &st->partials, (size_t)MSM_MAX_Y * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)))) return rc;
-    if ((rc = dev_alloc(c, &st->result, sizeof(Xyzz<Q>)))) return rc;
-    ZKT_HIP(c, hipHostMalloc(&st->host_result, sizeof(Xyzz<Q>)));
+    ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+    for (int i = 0; i < MsmState::SLOTS; ++i) {
+        if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
+        if ((rc = dev_alloc(c, &st->segA[i], nseg * sizeof(Xyzz<Q>)))) return rc;
+        if ((rc = dev_alloc(c, &st->segT[i], nseg * sizeof(Xyzz<Q>)))) return rc;
+        if ((rc = dev_alloc(c, &st->partials[i], (size_t)MSM_MAX_Y * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)))) return rc;
+        if ((rc = dev_alloc(c, &st->result[i], sizeof(Xyzz<Q>)))) return rc;
+        ZKT_HIP(c, hipHostMalloc(&st->host_result[i], sizeof(Xyzz<Q>)));
+        ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
+        ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_done[i], hipEventDisableTiming));
+    }
     c->msm = st;
     return ZKT_OK;
 }
@@ -465,9 +481,13 @@ static void msm_release(zkt_ctx* c) {
     if (!c->msm) return;
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {st.heavy, st.table, st.keys, st.keys2, st.vals, st.vals2, st.cub_tmp, st.offsets, st.pieces,
-                    st.buckets, st.segA, st.segT, st.partials, st.result};
+    if (st.side) (void)hipStreamSynchronize(st.side);
+    void* ptrs[] = {st.heavy, st.table, st.keys, st.keys2, st.vals, st.vals2, st.cub_tmp, st.offsets, st.pieces};
     for (void* p : ptrs) dev_free(c, p);
+    for (int i = 0; i < MsmState::SLOTS; ++i) {
+        dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
+        dev_free(c, st.partials[i]); dev_free(c, st.result[i]);
+    }
     c->msm.reset();
 }
 
@@ -529,12 +549,13 @@ static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count) {
 
 // enqueue the whole MSM; the XYZZ result lands in st.result
 template <class C>
-static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont) {
+static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0) {
     using Q = typename C::Fq;
     using R = typename C::Fr;
     MsmState& st = *c->msm;
     const uint32_t m = (uint32_t)((size_t)st.W * n);
-    ProfScope prof_all(c, "msm");
+    {
+    ProfScope prof_all(c, "msm_main");
     {
         unsigned blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_msm_digits<C>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<R>*)d_scalars, n, mont,
@@ -554,25 +575,51 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
                            st.vals2, m, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
+    // the slot's tail buffers may still be read by the previous MSM that used this slot
+    if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
     ZKT_HIP(c, hipMemsetAsync(st.heavy, 0, 4, c->stream));
     hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
-                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets, st.heavy);
+                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, c->stream, st.offsets,
-                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets, st.heavy);
+                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());
+    }
+    // ---- tail on the side stream: overlaps whatever the main stream does next ----
+    ZKT_HIP(c, hipEventRecord(st.ev_main[slot], c->stream));
+    ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[slot], 0));
+    {
+    ProfScope prof_tail(c, "msm_tail", st.side);
     const uint32_t nseg = st.B / MSM_SEG;
-    hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, c->stream,
-                       (const Xyzz<Q>*)st.buckets, nseg, (Xyzz<Q>*)st.segA, (Xyzz<Q>*)st.segT);
+    hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, st.side,
+                       (const Xyzz<Q>*)st.buckets[slot], nseg, (Xyzz<Q>*)st.segA[slot], (Xyzz<Q>*)st.segT[slot]);
     ZKT_HIP(c, hipGetLastError());
     int seg_bits = st.c - 1 - 3;  // log2(nseg)
     int ny = 1 + seg_bits;
-    hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny), dim3(256), 0, c->stream,
-                       (const Xyzz<Q>*)st.segA, (const Xyzz<Q>*)st.segT, nseg, (Xyzz<Q>*)st.partials);
+    hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny), dim3(256), 0, st.side,
+                       (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], nseg, (Xyzz<Q>*)st.partials[slot]);
     ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, c->stream, (const Xyzz<Q>*)st.partials, ny,
-                       MSM_R2_BLOCKS, (const Xyzz<Q>*)st.buckets + st.B, st.c, (Xyzz<Q>*)st.result);
+    hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, st.side, (const Xyzz<Q>*)st.partials[slot], ny,
+                       MSM_R2_BLOCKS, (const Xyzz<Q>*)st.buckets[slot] + st.B, st.c, (Xyzz<Q>*)st.result[slot]);
     ZKT_HIP(c, hipGetLastError());
+    }
+    ZKT_HIP(c, hipMemcpyAsync(st.host_result[slot], st.result[slot], sizeof(Xyzz<Q>), hipMemcpyDeviceToHost, st.side));
+    ZKT_HIP(c, hipEventRecord(st.ev_done[slot], st.side));
+    st.pending[slot] = true;
+    return ZKT_OK;
+}
+
+// waits for the MSM in `slot` and normalises its result on the host (one inversion; the affine
+// coordinates are needed there for the Fiat-Shamir transcript anyway)
+template <class C>
+static int msm_collect(zkt_ctx* c, int slot, Affine<typename C::Fq>* out) {
+    using Q = typename C::Fq;
+    MsmState& st = *c->msm;
+    ZKT_HIP(c, hipEventSynchronize(st.ev_done[slot]));
+    st.pending[slot] = false;
+    Xyzz<Q> r;
+    memcpy(&r, st.host_result[slot], sizeof(r));
+    *out = xyzz_to_affine<Q>(r);
     return ZKT_OK;
 }
 
@@ -589,17 +636,39 @@ static int msm_run_t(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_of
         res.x = fe_zero<Q>();
         res.y = fe_zero<Q>();
     } else {
-        int rc = msm_enqueue<C>(c, d_scalars, n, base_off, mont);
+        int rc = msm_enqueue<C>(c, d_scalars, n, base_off, mont, 0);
         if (rc) return rc;
-        ZKT_HIP(c, hipMemcpyAsync(st.host_result, st.result, sizeof(Xyzz<Q>), hipMemcpyDeviceToHost, c->stream));
-        ZKT_HIP(c, hipStreamSynchronize(c->stream));
-        Xyzz<Q> r;
-        memcpy(&r, st.host_result, sizeof(r));
-        res = xyzz_to_affine<Q>(r);  // one inversion, on the host (needed there for Fiat-Shamir)
+        if ((rc = msm_collect<C>(c, 0, &res))) return rc;
     }
     memcpy(out_xy, res.x.v, Q::N * 4);
     memcpy(out_xy + Q::N / 2, res.y.v, Q::N * 4);
     if (out_inf) *out_inf = aff_is_inf<Q>(res) ? 1 : 0;
+    return ZKT_OK;
+}
+
+// prover-facing batch form: begin up to MsmState::SLOTS commitments, then collect them
+int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot) {
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    if (slot < 0 || slot >= MsmState::SLOTS) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "bad MSM slot");
+    if (n == 0 || base_off > c->msm->count || n > c->msm->count - base_off)
+        return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
+    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue<Bn254Curve>(c, d_scalars, n, base_off, mont, slot);
+    return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont, slot);
+}
+int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy) {
+    if (c->curve == ZKT_CURVE_BN254) {
+        Affine<Bn254Fq> a;
+        int rc = msm_collect<Bn254Curve>(c, slot, &a);
+        if (rc) return rc;
+        memcpy(out_xy, a.x.v, 32);
+        memcpy(out_xy + 4, a.y.v, 32);
+        return ZKT_OK;
+    }
+    Affine<Bls381Fq> a;
+    int rc = msm_collect<Bls381Curve>(c, slot, &a);
+    if (rc) return rc;
+    memcpy(out_xy, a.x.v, 48);
+    memcpy(out_xy + 6, a.y.v, 48);
     return ZKT_OK;
 }
 

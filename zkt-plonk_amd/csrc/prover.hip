@@ -16,6 +16,8 @@ namespace zkt {
 
 // msm.hip
 int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf);
+int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot);
+int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy);
 
 enum { PK_QM = 0, PK_QL, PK_QR, PK_QO, PK_QC, PK_S1, PK_S2, PK_S3, PK_QLOOKUP, PK_QTABLE, PK_COUNT };
 // coset vectors kept on the device (keys/mod.rs:153-174; x and l_1 are stored, zh is 4 scalars)
@@ -131,13 +133,21 @@ struct Prover {
     }
     static void put(uint32_t dst[8], const F& v) { memcpy(dst, v.v, 32); }
 
-    int commit(const void* d_poly, size_t len, Affine<Q>* out) {
+    // commitments of one round are enqueued back to back (the bucket-reduction tail of one overlaps the
+    // accumulation of the next) and collected together
+    int commit_begin(const void* d_poly, size_t len, int slot) { return msm_begin(c, d_poly, len, 0, 1, slot); }
+    int commit_end(int slot, Affine<Q>* out) {
         uint64_t xy[12];
-        int rc = msm_g1_dev(c, d_poly, len, 0, 1, xy, nullptr);
+        int rc = msm_end(c, slot, xy);
         if (rc) return rc;
         memcpy(out->x.v, xy, Q::N * 4);
         memcpy(out->y.v, xy + Q::N / 2, Q::N * 4);
         return ZKT_OK;
+    }
+    int commit(const void* d_poly, size_t len, Affine<Q>* out) {
+        int rc = commit_begin(d_poly, len, 0);
+        if (rc) return rc;
+        return commit_end(0, out);
     }
 
     // iNTT of n evaluations into a zero-tailed coefficient buffer, trim, blind (prove.rs:120-127 etc.)
@@ -270,8 +280,9 @@ struct Prover {
         }
         Affine<Q> cm[11];
         static const char* L1[3] = {"a_commit", "b_commit", "c_commit"};
+        for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
         for (int k = 0; k < 3; ++k) {
-            if ((rc = commit(S.poly[k], n + 2, &cm[k]))) return rc;
+            if ((rc = commit_end(k, &cm[k]))) return rc;
             tr_commit(L1[k], cm[k]);
         }
 
@@ -283,9 +294,10 @@ struct Prover {
         if ((rc = combine_split(in.table, in.table_len))) return rc;
         if ((rc = evals_to_blinded_poly(S.ev[5], S.poly[4], 6, 3, 4))) return rc;          // h1: 3 blinders
         if ((rc = evals_to_blinded_poly(S.ev[6], S.poly[5], 9, 2, 5))) return rc;          // h2: 2 blinders
-        if ((rc = commit(S.poly[3], n, &cm[3]))) return rc;
-        if ((rc = commit(S.poly[4], n + 3, &cm[4]))) return rc;
-        if ((rc = commit(S.poly[5], n + 2, &cm[5]))) return rc;
+        if ((rc = commit_begin(S.poly[3], n, 0))) return rc;
+        if ((rc = commit_begin(S.poly[4], n + 3, 1))) return rc;
+        if ((rc = commit_begin(S.poly[5], n + 2, 2))) return rc;
+        for (int k = 0; k < 3; ++k) if ((rc = commit_end(k, &cm[3 + k]))) return rc;
         tr_commit("t_commit", cm[3]);
         tr_commit("h1_commit", cm[4]);
         tr_commit("h2_commit", cm[5]);
@@ -326,8 +338,9 @@ struct Prover {
             if ((rc = z_combine(c, S.sc[2], S.sc[3], inv.v, S.ev[7], n))) return rc;
         }
         if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[7], 14, 3, 7))) return rc;         // z2: 3 blinders
-        if ((rc = commit(S.poly[6], n + 3, &cm[6]))) return rc;
-        if ((rc = commit(S.poly[7], n + 3, &cm[7]))) return rc;
+        if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
+        if ((rc = commit_begin(S.poly[7], n + 3, 1))) return rc;
+        for (int k = 0; k < 2; ++k) if ((rc = commit_end(k, &cm[6 + k]))) return rc;
         tr_commit("z1_commit", cm[6]);
         tr_commit("z2_commit", cm[7]);
 
@@ -361,9 +374,8 @@ struct Prover {
                 return rc;
             if ((rc = check_status())) return rc;
         }
-        if ((rc = commit(S.poly[9], n + 3, &cm[8]))) return rc;
-        if ((rc = commit(S.poly[10], n + 3, &cm[9]))) return rc;
-        if ((rc = commit(S.poly[11], n + 3, &cm[10]))) return rc;
+        for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[9 + k], n + 3, k))) return rc;
+        for (int k = 0; k < 3; ++k) if ((rc = commit_end(k, &cm[8 + k]))) return rc;
         tr_commit("q_lo_commit", cm[8]);
         tr_commit("q_mid_commit", cm[9]);
         tr_commit("q_hi_commit", cm[10]);
@@ -479,7 +491,7 @@ struct Prover {
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv<R>(xi);
             if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
-            if ((rc = commit(S.sc[3], cap - 1, &aw))) return rc;
+            if ((rc = commit_begin(S.sc[3], cap - 1, 0))) return rc;  // the scalars are consumed by the first kernel
         }
         {   // saw opening (prove.rs:427-451): (z1, z2, t, h1) at xi * omega
             LinCombArgs lo{};
@@ -493,7 +505,9 @@ struct Prover {
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv<R>(shifted);
             if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
-            if ((rc = commit(S.sc[3], cap - 1, &saw))) return rc;
+            if ((rc = commit_begin(S.sc[3], cap - 1, 1))) return rc;
+            if ((rc = commit_end(0, &aw))) return rc;
+            if ((rc = commit_end(1, &saw))) return rc;
         }
 
         // ---- Proof (proof.rs:106-155), CanonicalSerialize ----
