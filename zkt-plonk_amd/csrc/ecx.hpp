@@ -81,9 +81,11 @@ ZKT_HD XyzzX<Q> xx_double(const XyzzX<Q>& p) {
     return r;
 }
 
-// madd-2008-s; q canonical, not the point at infinity
-template <class Q>
+// madd-2008-s; q canonical, not the point at infinity.  This is the body of the MSM accumulation loop:
+// its ten products are inlined (INL) there, everything else calls the shared product.
+template <class Q, bool INL = false>
 ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
+    auto mul = [](const Fx<Q>& a, const Fx<Q>& b) { return INL ? fx_mul_inl<Q>(a, b) : fx_mul<Q>(a, b); };
     if (p.inf) {
         XyzzX<Q> r;
         r.x = q.x;
@@ -93,22 +95,23 @@ ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
         r.inf = false;
         return r;
     }
-    const Fx<Q> u2 = fx_mul<Q>(q.x, p.zz);
-    const Fx<Q> s2 = fx_mul<Q>(q.y, p.zzz);
+    const Fx<Q> u2 = mul(q.x, p.zz);
+    const Fx<Q> s2 = mul(q.y, p.zzz);
     const Fx<Q> pp_ = fx_sub<Q, 8>(u2, p.x);           // < 10p
     const Fx<Q> rr = fx_sub<Q, 4>(s2, p.y);            // < 6p
-    const Fx<Q> pp = fx_sqr<Q>(pp_);                   // 100 p^2
+    const Fx<Q> pp = mul(pp_, pp_);                    // 100 p^2
+    const Fx<Q> rr2 = mul(rr, rr);
     if (fx_is_zero_lt2p<Q>(pp)) {                      // same x: P == Q or P == -Q
-        if (fx_is_zero_lt2p<Q>(fx_sqr<Q>(rr))) return xx_double_affine<Q>(q);
+        if (fx_is_zero_lt2p<Q>(rr2)) return xx_double_affine<Q>(q);
         return xx_identity<Q>();
     }
-    const Fx<Q> ppp = fx_mul<Q>(pp_, pp);
-    const Fx<Q> qq = fx_mul<Q>(p.x, pp);
+    const Fx<Q> ppp = mul(pp_, pp);
+    const Fx<Q> qq = mul(p.x, pp);
     XyzzX<Q> r;
-    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(fx_sqr<Q>(rr), ppp), fx_dbl<Q>(qq));        // < 8p
-    r.y = fx_sub<Q, 2>(fx_mul<Q>(rr, fx_sub<Q, 8>(qq, r.x)), fx_mul<Q>(p.y, ppp));  // 6p * 10p ; < 4p
-    r.zz = fx_mul<Q>(p.zz, pp);
-    r.zzz = fx_mul<Q>(p.zzz, ppp);
+    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(rr2, ppp), fx_dbl<Q>(qq));                   // < 8p
+    r.y = fx_sub<Q, 2>(mul(rr, fx_sub<Q, 8>(qq, r.x)), mul(p.y, ppp));           // 6p * 10p ; < 4p
+    r.zz = mul(p.zz, pp);
+    r.zzz = mul(p.zzz, ppp);
     r.inf = false;
     return r;
 }

@@ -274,8 +274,9 @@ struct FxVec {
     typedef uint32_t type __attribute__((ext_vector_type(FxP<P>::L)));
 };
 
+// fully inlined product (for the one or two loops that are hot enough to own a private copy)
 template <class P>
-ZKT_MUL typename FxVec<P>::type fx_mul_raw(typename FxVec<P>::type a, typename FxVec<P>::type b) {
+ZKT_HD Fx<P> fx_mul_inl(const Fx<P>& a, const Fx<P>& b) {
     constexpr int L = FxP<P>::L;
     uint64_t t[L + 1];
 #pragma unroll
@@ -283,7 +284,7 @@ ZKT_MUL typename FxVec<P>::type fx_mul_raw(typename FxVec<P>::type a, typename F
 #pragma unroll
     for (int i = 0; i < L; ++i) {
 #pragma unroll
-        for (int j = 0; j < L; ++j) t[j] += (uint64_t)a[j] * b[i];
+        for (int j = 0; j < L; ++j) t[j] += (uint64_t)a.l[j] * b.l[i];
         const uint32_t m = ((uint32_t)t[0] * FxP<P>::INV) & FxP<P>::MASK;
 #pragma unroll
         for (int j = 0; j < L; ++j) t[j] += (uint64_t)m * FxP<P>::mod(j);
@@ -293,15 +294,31 @@ ZKT_MUL typename FxVec<P>::type fx_mul_raw(typename FxVec<P>::type a, typename F
         t[0] += carry;
         t[L] = 0;
     }
-    typename FxVec<P>::type r;
+    Fx<P> r;
     uint64_t c = 0;
 #pragma unroll
     for (int j = 0; j < L - 1; ++j) {
         uint64_t x = t[j] + c;
-        r[j] = (uint32_t)x & FxP<P>::MASK;
+        r.l[j] = (uint32_t)x & FxP<P>::MASK;
         c = x >> 29;
     }
-    r[L - 1] = (uint32_t)(t[L - 1] + c);
+    r.l[L - 1] = (uint32_t)(t[L - 1] + c);
+    return r;
+}
+
+template <class P>
+ZKT_MUL typename FxVec<P>::type fx_mul_raw(typename FxVec<P>::type a, typename FxVec<P>::type b) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> x, y;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        x.l[i] = a[i];
+        y.l[i] = b[i];
+    }
+    const Fx<P> z = fx_mul_inl<P>(x, y);
+    typename FxVec<P>::type r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r[i] = z.l[i];
     return r;
 }
 

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, co
             q.x = fx_unpack<Q>(cx);
             q.y = fx_unpack<Q>(cy);
             if (vcur >> 31) q.y = fx_sub<Q, 1>(fx_zero<Q>(), q.y);  // -y = p - y
-            acc = xx_add_mixed<Q>(acc, q);
+            acc = xx_add_mixed<Q, true>(acc, q);
         }
     }
     xx_store<Q>(pieces + (size_t)t + cur, acc);
