@@ -47,6 +47,11 @@ struct CircuitState {
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
+    // The table polynomial depends on the lookup table only: while consecutive proofs pass the same table its
+    // evaluations, coefficients, 4n-coset and commitment are reused (one MSM and two transforms less).
+    std::vector<uint64_t> cached_table;
+    bool t_cached = false, t_coset_valid = false;
+    uint64_t t_commit_xy[12] = {};
 };
 
 // ---- host field helpers ------------------------------------------------------------------------------
@@ -287,17 +292,33 @@ struct Prover {
         }
 
         // ---- round 2 (prove.rs:145-185) ----
-        ZKT_HIP(c, hipMemsetAsync(S.ev[3], 0, n * 32, c->stream));
-        if (in.table_len) ZKT_HIP(c, hipMemcpyAsync(S.ev[3], in.table, in.table_len * 32, hipMemcpyHostToDevice, c->stream));
-        if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;          // t: no blinders
+        const bool same_table = S.t_cached && S.cached_table.size() == 4 * in.table_len &&
+                                (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
+        if (!same_table) {
+            S.t_cached = false;
+            S.t_coset_valid = false;
+            ZKT_HIP(c, hipMemsetAsync(S.ev[3], 0, n * 32, c->stream));
+            if (in.table_len) ZKT_HIP(c, hipMemcpyAsync(S.ev[3], in.table, in.table_len * 32, hipMemcpyHostToDevice, c->stream));
+            if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;      // t: no blinders
+        }
         if ((rc = poly_mul_vec(c, S.q_lookup_ev, S.ev[2], S.ev[4], n))) return rc;         // f = q_lookup . c
         if ((rc = combine_split(in.table, in.table_len))) return rc;
         if ((rc = evals_to_blinded_poly(S.ev[5], S.poly[4], 6, 3, 4))) return rc;          // h1: 3 blinders
         if ((rc = evals_to_blinded_poly(S.ev[6], S.poly[5], 9, 2, 5))) return rc;          // h2: 2 blinders
-        if ((rc = commit_begin(S.poly[3], n, 0))) return rc;
+        if (!same_table && (rc = commit_begin(S.poly[3], n, 0))) return rc;
         if ((rc = commit_begin(S.poly[4], n + 3, 1))) return rc;
         if ((rc = commit_begin(S.poly[5], n + 2, 2))) return rc;
-        for (int k = 0; k < 3; ++k) if ((rc = commit_end(k, &cm[3 + k]))) return rc;
+        if (!same_table) {
+            if ((rc = commit_end(0, &cm[3]))) return rc;
+            memcpy(S.t_commit_xy, cm[3].x.v, Q::N * 4);
+            memcpy(S.t_commit_xy + Q::N / 2, cm[3].y.v, Q::N * 4);
+            S.cached_table.assign(in.table, in.table + 4 * in.table_len);
+            S.t_cached = true;
+        } else {
+            memcpy(cm[3].x.v, S.t_commit_xy, Q::N * 4);
+            memcpy(cm[3].y.v, S.t_commit_xy + Q::N / 2, Q::N * 4);
+        }
+        for (int k = 1; k < 3; ++k) if ((rc = commit_end(k, &cm[3 + k]))) return rc;
         tr_commit("t_commit", cm[3]);
         tr_commit("h1_commit", cm[4]);
         tr_commit("h2_commit", cm[5]);
@@ -355,8 +376,11 @@ struct Prover {
         {
             // quotient_poly.rs:52-96 -- nine coset transforms on the 4n domain
             const int src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
-            for (int k = 0; k < W_COUNT; ++k)
+            for (int k = 0; k < W_COUNT; ++k) {
+                if (k == W_T && S.t_coset_valid) continue;  // unchanged table: its coset is still resident
                 if ((rc = ntt_run(c, log_n + 2, 0, 1, S.poly[src[k]], n + 8, S.wcos[k]))) return rc;
+            }
+            S.t_coset_valid = S.t_cached;
             QuotientArgs q{};
             q.a = S.wcos[W_A]; q.b = S.wcos[W_B]; q.c = S.wcos[W_C]; q.pi = S.wcos[W_PI];
             q.z1 = S.wcos[W_Z1]; q.z2 = S.wcos[W_Z2]; q.t = S.wcos[W_T]; q.h1 = S.wcos[W_H1]; q.h2 = S.wcos[W_H2];
