@@ -23,11 +23,11 @@ __global__ void k_mul_vec(const Fe<P>* a, const Fe<P>* b, Fe<P>* o, size_t n) {
 
 // number of coefficients after stripping trailing zeros (DensePolynomial::from_coefficients_vec)
 template <class P>
-__global__ void k_trim_len(const Fe<P>* p, size_t lo, size_t n, uint32_t* len) {
+__global__ void k_trim_len(const Fe<P>* p, size_t lo, size_t n, uint32_t* len, int skip_if_set) {
     // Scans [lo, n).  The polynomials are dense, so the answer is almost always in the last few hundred
     // coefficients: the caller first scans that tail with one small launch and this launch returns at once
     // when the tail already produced a result (same-address atomics serialise at ~13 ns each).
-    if (lo == 0 && *len != 0) return;
+    if (skip_if_set && *len != 0) return;  // only the follow-up launch may do this: len is final by then
     size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t v = 0;
     if (i < n && !fe_is_zero<P>(fe_load<P>(p + i))) v = (uint32_t)(i + 1);
@@ -472,10 +472,10 @@ template <class P> static int trim_len_t(zkt_ctx* c, const void* p, size_t n, ui
     ZKT_HIP(c, hipMemsetAsync(d_len, 0, 4, c->stream));
     if (!n) return ZKT_OK;
     const size_t tail = n > 1024 ? n - 1024 : 0;
-    hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(n - tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, tail, n, d_len);
+    hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(n - tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, tail, n, d_len, 0);
     ZKT_HIP(c, hipGetLastError());
     if (tail) {  // full scan, a no-op unless the top 1024 coefficients were all zero
-        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, (size_t)0, tail, d_len);
+        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, (size_t)0, tail, d_len, 1);
         ZKT_HIP(c, hipGetLastError());
     }
     return ZKT_OK;
@@ -565,7 +565,7 @@ template <class P> static int quot_split_t(zkt_ctx* c, const void* q, size_t n, 
     {   // only "is anything non-zero at or above 3(n+2)?" matters for the quotient itself
         ZKT_HIP(c, hipMemsetAsync(lens + 3, 0, 4, c->stream));
         const size_t lo = 3 * chunk, hi = 4 * n;
-        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(hi - lo)), dim3(256), 0, c->stream, (const Fe<P>*)q, lo, hi, lens + 3);
+        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(hi - lo)), dim3(256), 0, c->stream, (const Fe<P>*)q, lo, hi, lens + 3, 0);
         ZKT_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_quot_blind<P>, dim3(1), dim3(64), 0, c->stream, (Fe<P>*)lo, (Fe<P>*)mid, (Fe<P>*)hi, lens, (const Fe<P>*)b0b1, (uint32_t)n, d_status);
