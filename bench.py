@@ -141,11 +141,18 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one process per GPU over RCCL; ZKT_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
+        backend = os.environ.get("ZKT_DIST_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     fld = FIELDS[args.curve]
     log_n, n = args.log_n, 1 << args.log_n
@@ -209,7 +216,8 @@ def main():
     prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "msm_main", "msm_tail", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2),
                                             "ntt_pass", "quotient")}
     ctx.profile_enable(False)
-    elapsed = par.max_over_ranks(dist, elapsed, dev)   # whole-job time = slowest rank
+    red_dev = dev if (dist is None or dist.get_backend() == "nccl") else None
+    elapsed = par.max_over_ranks(dist, elapsed, red_dev)   # whole-job time = slowest rank
     assert proof is not None and len(proof) == (802 if args.curve == "bn254" else 1010)
 
     total_proofs = args.steps * world

@@ -71,6 +71,41 @@ def test_synthetic_circuits_match_oracle(cv, gates, table_size, ctxs):
     assert P.verify(cv, tau, vk, want, P.new_seeded_transcript(cv, vk), pis)
 
 
+def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
+    """Second and third proof on the same loaded circuit take the cached-table path (same table), then a
+    different table invalidates the cache; every proof must still equal the oracle's bytes."""
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 300, 32, seed=21)
+    n = cs.circuit_bound()
+    tau = 31337
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    ctx.srs_load(srs_arr)
+    prover = z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+    a, b, c = cs.wire_evals(cs.n_gates)
+    pi = {pos: K.fr_to_mont(cv, [v])[0] for pos, v in cs.pi.items()}
+    for rep, seed in enumerate((3, 4, 5)):
+        blinders = field_elems(cv.fr.p, seed, P.NUM_BLINDERS)
+        want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+        tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)
+        got = prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
+                           pi, K.fr_to_mont(cv, blinders), tr)
+        assert got == want, rep
+    # same circuit, table extended by one unused value: t changes, the cache must not be used
+    cs2 = P.ConstraintSystem.__new__(P.ConstraintSystem)
+    cs2.__dict__.update(cs.__dict__)
+    cs2.table = list(cs.table) + [123456789]
+    blinders = field_elems(cv.fr.p, 6, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs2, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)
+    got = prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs2.table),
+                       pi, K.fr_to_mont(cv, blinders), tr)
+    assert got == want
+
+
 def test_ethereum_transcript_proof_matches_oracle(ctxs):
     import zkt_plonk_amd as z
     cv = F.BN254
