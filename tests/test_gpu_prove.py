@@ -94,10 +94,11 @@ def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
         got = prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
                            pi, K.fr_to_mont(cv, blinders), tr)
         assert got == want, rep
-    # same circuit, table extended by one unused value: t changes, the cache must not be used
+    # same circuit, two table entries swapped: t changes (same set), the cache must not be used
     cs2 = P.ConstraintSystem.__new__(P.ConstraintSystem)
     cs2.__dict__.update(cs.__dict__)
-    cs2.table = list(cs.table) + [123456789]
+    cs2.table = list(cs.table)
+    cs2.table[0], cs2.table[1] = cs2.table[1], cs2.table[0]
     blinders = field_elems(cv.fr.p, 6, P.NUM_BLINDERS)
     want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs2, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
     tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)

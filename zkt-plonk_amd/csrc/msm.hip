@@ -25,7 +25,8 @@
 
 namespace zkt {
 
-constexpr int MSM_CHUNK = 64;   // sorted entries per accumulation thread
+constexpr int MSM_CHUNK_MIN = 16;  // sorted entries per accumulation thread: at least this many; the actual
+                                   // chunk is sized so that ONE resident wave-front of threads covers the array
 constexpr int MSM_SEG = 8;      // buckets per running-sum segment
 constexpr int MSM_R2_BLOCKS = 4;
 constexpr int MSM_MAX_Y = 24;
@@ -64,6 +65,7 @@ struct MsmState {
     void* partials[SLOTS] = {};     // Xyzz[MAX_Y * R2_BLOCKS]
     void* result[SLOTS] = {};       // Xyzz
     void* host_result[SLOTS] = {};  // pinned
+    size_t acc_threads = 196608;   // resident threads of k_msm_accumulate (occupancy query at setup)
     hipStream_t side = nullptr;
     hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
     bool pending[SLOTS] = {};
@@ -195,15 +197,15 @@ __global__ void k_msm_offsets(const uint32_t* keys, uint32_t m, uint32_t B, uint
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t m,
-                                                        const uint32_t* offsets,
+                                                        uint32_t chunk, const uint32_t* offsets,
                                                         const Affine<typename C::Fq>* table,
                                                         Xyzz<typename C::Fq>* pieces) {
     using Q = typename C::Fq;
     const uint32_t base = offsets[1];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t p0 = (uint64_t)base + (uint64_t)t * MSM_CHUNK;
+    const uint64_t p0 = (uint64_t)base + (uint64_t)t * chunk;
     if (p0 >= m) return;
-    const uint32_t p1 = (uint32_t)((p0 + MSM_CHUNK < m) ? p0 + MSM_CHUNK : m);
+    const uint32_t p1 = (uint32_t)((p0 + chunk < m) ? p0 + chunk : m);
     uint32_t cur = keys[p0];
     XyzzX<Q> acc = xx_identity<Q>();
     uint32_t v = vals[p0];
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, co
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B,
+__global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B, uint32_t chunk,
                                                         const Xyzz<typename C::Fq>* pieces,
                                                         Xyzz<typename C::Fq>* buckets, uint32_t* heavy) {
     using Q = typename C::Fq;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets,
         const uint32_t base = offsets[1];
         const uint32_t s = offsets[b], e = offsets[b + 1];
         if (e > s) {
-            const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+            const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
             if (t1 - t0 >= MSM_HEAVY) {  // crowded bucket: leave it to k_msm_heavy
                 heavy[1 + atomicAdd(heavy, 1u)] = b;
                 return;
@@ -297,7 +299,8 @@ ZKT_D XyzzX<Q> block_sum_256(XyzzX<Q> acc, Xyzz<Q>* wsum) {
 
 // crowded buckets (skewed digit distributions): one block folds all pieces of one bucket
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, const Xyzz<typename C::Fq>* pieces,
+__global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, uint32_t chunk,
+                                                   const Xyzz<typename C::Fq>* pieces,
                                                    Xyzz<typename C::Fq>* buckets, const uint32_t* heavy) {
     using Q = typename C::Fq;
     __shared__ Xyzz<Q> wsum[4];
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, cons
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const uint32_t b = heavy[1 + h];
         const uint32_t s = offsets[b], e = offsets[b + 1];
-        const uint32_t t0 = (s - base) / MSM_CHUNK, t1 = (e - 1 - base) / MSM_CHUNK;
+        const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
         XyzzX<Q> acc = xx_identity<Q>();
         for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xx_add<Q>(acc, xx_load<Q>(pieces + (size_t)t + b));
         acc = block_sum_256<Q>(acc, wsum);
@@ -444,9 +447,17 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((rc = dev_alloc(c, &st->cub_tmp, st->cub_bytes + 256))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->B + 2) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
-    size_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
+    size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
     if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(Xyzz<Q>)))) return rc;
     size_t nseg = st->B / MSM_SEG;
+    {
+        int blocks_per_cu = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_msm_accumulate<C>, 256, 0) == hipSuccess &&
+            blocks_per_cu > 0 && cus > 0)
+            st->acc_threads = (size_t)blocks_per_cu * cus * 256;
+    }
     ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
@@ -554,6 +565,10 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     using R = typename C::Fr;
     MsmState& st = *c->msm;
     const uint32_t m = (uint32_t)((size_t)st.W * n);
+    // one chunk per thread, and exactly as many threads as the chip keeps resident for this kernel: the
+    // whole array is consumed in a single wave-front with no partially filled last round
+    uint32_t chunk = (uint32_t)((m + st.acc_threads - 1) / st.acc_threads);
+    if (chunk < (uint32_t)MSM_CHUNK_MIN) chunk = MSM_CHUNK_MIN;
     {
     ProfScope prof_all(c, "msm_main");
     {
@@ -570,18 +585,18 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     ZKT_HIP(c, hipGetLastError());
     {
         ProfScope prof_acc(c, "msm_accumulate");
-        uint32_t max_chunks = (m + MSM_CHUNK - 1) / MSM_CHUNK;
+        uint32_t max_chunks = (m + chunk - 1) / chunk;
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.keys2,
-                           st.vals2, m, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
+                           st.vals2, m, chunk, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
     // the slot's tail buffers may still be read by the previous MSM that used this slot
     if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
     ZKT_HIP(c, hipMemsetAsync(st.heavy, 0, 4, c->stream));
     hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
-                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
+                       chunk, (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, c->stream, st.offsets,
+    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, c->stream, st.offsets, chunk,
                        (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());
     }
