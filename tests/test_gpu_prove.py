@@ -157,3 +157,77 @@ def test_prover_error_paths(ctxs):
         prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
                      {p_: K.fr_to_mont(cv, [v])[0] for p_, v in cs.pi.items()}, K.fr_to_mont(cv, blinders), tr)
     assert e.value.code == 5
+
+
+def test_foreign_transcript_callbacks(ctxs):
+    """zkt_prove_with: the transcript lives on the caller's side (the Rust shim's T: TranscriptProtocol);
+    here the four callbacks are Python functions driving the oracle's Merlin, fed with Montgomery limbs."""
+    import ctypes
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd._lib import ProveInputs, u64p
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 120, 16, seed=33)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, 99991, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(cv.fr.p, 12, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    ctx.srs_load(srs_arr)
+    z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+
+    tr = P.new_seeded_transcript(cv, vk)   # the "foreign" transcript object
+    p, q = cv.fr.p, cv.fq.p
+    rinv_r, rinv_q = pow(1 << 256, -1, p), pow(1 << 256, -1, q)
+    R = (1 << 256) % p
+
+    def limbs(ptr, k):
+        return sum(int(ptr[i]) << (64 * (i - 4 * k)) for i in range(4 * k, 4 * k + 4))
+
+    U64 = ctypes.POINTER(ctypes.c_uint64)
+    CB_U64 = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64)
+    CB_SC = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_char_p, U64, ctypes.c_size_t, ctypes.c_int)
+    CB_CM = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_char_p, U64, ctypes.c_int)
+    CB_CH = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_char_p, U64)
+
+    def cb_u64(user, label, v):
+        tr.append_u64(label.decode(), v)
+
+    def cb_sc(user, label, ptr, count, single):
+        vals = [limbs(ptr, k) * rinv_r % p for k in range(count)]
+        if single:
+            tr.append_scalar(label.decode(), vals[0])
+        else:
+            tr.append_scalars(label.decode(), vals)
+
+    def cb_cm(user, label, ptr, inf):
+        pt = None if inf else (limbs(ptr, 0) * rinv_q % q, limbs(ptr, 1) * rinv_q % q)
+        tr.append_commitment(label.decode(), pt)
+
+    def cb_ch(user, label, out):
+        v = tr.challenge_scalar(label.decode()) * R % p
+        for i in range(4):
+            out[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+
+    class VT(ctypes.Structure):
+        _fields_ = [("user", ctypes.c_void_p), ("append_u64", CB_U64), ("append_scalars", CB_SC),
+                    ("append_commitment", CB_CM), ("challenge_scalar", CB_CH)]
+
+    vt = VT(None, CB_U64(cb_u64), CB_SC(cb_sc), CB_CM(cb_cm), CB_CH(cb_ch))
+    a, b, c = (K.fr_to_mont(cv, x) for x in cs.wire_evals(cs.n_gates))
+    table = K.fr_to_mont(cv, cs.table)
+    pos = sorted(cs.pi)
+    pi_vals = K.fr_to_mont(cv, [cs.pi[k] for k in pos])
+    bl = K.fr_to_mont(cv, blinders)
+    posarr = (ctypes.c_size_t * len(pos))(*pos)
+    inp = ProveInputs(u64p(a), u64p(b), u64p(c), a.shape[0], u64p(table), table.shape[0], posarr, u64p(pi_vals),
+                      len(pos), u64p(bl), 0)
+    out = (ctypes.c_uint8 * 2048)()
+    ln = ctypes.c_size_t(0)
+    L = z.lib()
+    L.zkt_prove_with.argtypes = [ctypes.c_void_p, ctypes.POINTER(ProveInputs), ctypes.POINTER(VT),
+                                 ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    rc = L.zkt_prove_with(ctx.handle, ctypes.byref(inp), ctypes.byref(vt), out, 2048, ctypes.byref(ln))
+    assert rc == 0, L.zkt_last_error(ctx.handle)
+    assert bytes(out[:ln.value]) == want
