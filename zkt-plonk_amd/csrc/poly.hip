@@ -263,59 +263,96 @@ __global__ void k_z_combine(const Fe<P>* pn, const Fe<P>* sd, Fe<P> inv_total, F
 // ---------------------------------------------------------------------------------------------
 // quotient: one fused pass over the 4n coset (quotient_poly.rs:98-224)
 // ---------------------------------------------------------------------------------------------
+// Arithmetic runs on 29-bit limbs (fx.hpp) without leaving them between products.  Two Montgomery scalings
+// are in play: values read from memory are arkworks' x R ("A"), host-prepared scalars and the selector
+// tables converted by to_hat_form() are x R' = x R 2^5 ("H").  fx_mul(A, H) = A; fx_mul(A, A) = A / 32, and every
+// such loss is made good by a power of 32 folded into a scalar (or the q_m table) of the same product.
+struct FxArg {
+    uint32_t l[9];
+};
+struct QuotientDev {
+    const void *a, *b, *c, *pi, *z1, *z2, *t, *h1, *h2;
+    const void *q_m, *q_l, *q_r, *q_o, *q_c, *q_lookup, *q_table, *sigma1, *sigma2, *sigma3, *x, *l1;
+    void* out;
+    FxArg beta, delta, alpha_k3, alpha2, alpha3_opd_k2, alpha3_k2, alpha4, alpha5;  // H (times 32^k where named _kN)
+    FxArg gamma, epsilon, eopd;                                                    // A
+    FxArg zh_inv[4];                                                               // H
+    uint64_t n4;
+};
 template <class P>
-__global__ __launch_bounds__(256) void k_quotient(QuotientArgs q) {
+ZKT_D Fx<P> arg_fx(const FxArg& w) {
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = w.l[i];
+    return r;
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
+    static_assert(FxP<P>::L == 9, "scalar field limbs");
+    typedef Fx<P> X;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.n4) return;
     const uint64_t j = (i + 4 < q.n4) ? i + 4 : i + 4 - q.n4;  // "omega-next" on the 4n coset
-#define LD(ptr, idx) fe_load<P>((const Fe<P>*)(ptr) + (idx))
-    const Fe<P> alpha = arg_fe<P>(q.alpha), beta = arg_fe<P>(q.beta), gamma = arg_fe<P>(q.gamma),
-                delta = arg_fe<P>(q.delta), eps = arg_fe<P>(q.epsilon);
-    const Fe<P> a = LD(q.a, i), b = LD(q.b, i), c = LD(q.c, i);
-    // keys/arithmetic.rs:67-81
-    Fe<P> acc = fe_mul<P>(fe_mul<P>(a, b), LD(q.q_m, i));
-    acc = fe_add<P>(acc, fe_mul<P>(a, LD(q.q_l, i)));
-    acc = fe_add<P>(acc, fe_mul<P>(b, LD(q.q_r, i)));
-    acc = fe_add<P>(acc, fe_mul<P>(c, LD(q.q_o, i)));
-    acc = fe_add<P>(acc, LD(q.q_c, i));
-    acc = fe_add<P>(acc, LD(q.pi, i));
+#define LD(ptr, idx) fx_unpack<P>(fe_load<P>((const Fe<P>*)(ptr) + (idx)))   // canonical, < p
+    const X beta = arg_fx<P>(q.beta), delta = arg_fx<P>(q.delta), gamma = arg_fx<P>(q.gamma);
+    const X a = LD(q.a, i), b = LD(q.b, i), c = LD(q.c, i);
+    // keys/arithmetic.rs:67-81 ; q_m is stored as H * 32
+    X acc = fx_mul<P>(fx_mul<P>(a, b), LD(q.q_m, i));
+    acc = fx_add<P>(acc, fx_mul<P>(a, LD(q.q_l, i)));
+    acc = fx_add<P>(acc, fx_mul<P>(b, LD(q.q_r, i)));
+    acc = fx_add<P>(acc, fx_mul<P>(c, LD(q.q_o, i)));
+    acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), LD(q.pi, i)));                 // < 10p
     // keys/permutation.rs:97-137
-    const Fe<P> z1 = LD(q.z1, i), z1n = LD(q.z1, j), l1 = LD(q.l1, i);
-    const Fe<P> ag = fe_add<P>(a, gamma), bg = fe_add<P>(b, gamma), cg = fe_add<P>(c, gamma);
+    const X z1 = LD(q.z1, i), z1n = LD(q.z1, j), l1 = LD(q.l1, i);
+    const X ag = fx_add<P>(a, gamma), bg = fx_add<P>(b, gamma), cg = fx_add<P>(c, gamma);   // < 2p
+    const X one = fx_const_to_ark<P>();                                          // 1 in A form
     {
-        const Fe<P> bx = fe_mul<P>(beta, LD(q.x, i));
-        const Fe<P> d2 = fe_dbl<P>(bx), d4 = fe_dbl<P>(d2), d8 = fe_dbl<P>(d4);
-        Fe<P> p1 = fe_mul<P>(alpha, z1);
-        p1 = fe_mul<P>(p1, fe_add<P>(bx, ag));
-        p1 = fe_mul<P>(p1, fe_add<P>(fe_sub<P>(d8, bx), bg));
-        p1 = fe_mul<P>(p1, fe_add<P>(fe_add<P>(fe_add<P>(d8, d4), bx), cg));
-        Fe<P> p2 = fe_mul<P>(alpha, z1n);
-        p2 = fe_mul<P>(p2, fe_add<P>(fe_mul<P>(beta, LD(q.sigma1, i)), ag));
-        p2 = fe_mul<P>(p2, fe_add<P>(fe_mul<P>(beta, LD(q.sigma2, i)), bg));
-        p2 = fe_mul<P>(p2, fe_add<P>(fe_mul<P>(beta, LD(q.sigma3, i)), cg));
-        const Fe<P> a2 = fe_sqr<P>(alpha);
-        Fe<P> p3 = fe_mul<P>(fe_mul<P>(fe_sub<P>(z1, fe_one<P>()), l1), a2);
-        acc = fe_add<P>(acc, fe_add<P>(fe_sub<P>(p1, p2), p3));
-        // keys/lookup.rs:81-122
-        const Fe<P> a3 = fe_mul<P>(a2, alpha), a4 = fe_mul<P>(a3, alpha), a5 = fe_mul<P>(a4, alpha);
-        const Fe<P> opd = fe_add<P>(delta, fe_one<P>());
-        const Fe<P> eopd = fe_mul<P>(eps, opd);
-        const Fe<P> z2 = LD(q.z2, i), z2n = LD(q.z2, j);
-        const Fe<P> t = LD(q.t, i), tn = LD(q.t, j), h1 = LD(q.h1, i), h1n = LD(q.h1, j), h2 = LD(q.h2, i);
-        Fe<P> k1 = fe_mul<P>(fe_mul<P>(a3, z2), opd);
-        k1 = fe_mul<P>(k1, fe_add<P>(eps, fe_mul<P>(LD(q.q_lookup, i), c)));
-        k1 = fe_mul<P>(k1, fe_add<P>(fe_add<P>(eopd, t), fe_mul<P>(delta, tn)));
-        Fe<P> k2 = fe_mul<P>(a3, z2n);
-        k2 = fe_mul<P>(k2, fe_add<P>(fe_add<P>(eopd, h1), fe_mul<P>(delta, h2)));
-        k2 = fe_mul<P>(k2, fe_add<P>(fe_add<P>(eopd, h2), fe_mul<P>(delta, h1n)));
-        Fe<P> k3 = fe_mul<P>(fe_mul<P>(a4, fe_sub<P>(z2, fe_one<P>())), l1);
-        Fe<P> k4 = fe_mul<P>(fe_mul<P>(a5, LD(q.q_table, i)), t);
-        acc = fe_add<P>(acc, fe_add<P>(fe_add<P>(fe_sub<P>(k1, k2), k3), k4));
+        const X bx = fx_mul<P>(LD(q.x, i), beta);                                // < 2p
+        const X d2 = fx_dbl<P>(bx), d4 = fx_dbl<P>(d2), d8 = fx_dbl<P>(d4);      // 4p, 8p, 16p
+        const X ak3 = arg_fx<P>(q.alpha_k3);
+        X p1 = fx_mul<P>(z1, ak3);
+        p1 = fx_mul<P>(p1, fx_add<P>(bx, ag));
+        p1 = fx_mul<P>(p1, fx_add<P>(fx_sub<P, 2>(d8, bx), bg));                 // 2p * 20p
+        p1 = fx_mul<P>(p1, fx_add<P>(fx_add<P>(fx_add<P>(d8, d4), bx), cg));     // 2p * 28p < R'
+        X p2 = fx_mul<P>(z1n, ak3);
+        p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma1, i), beta), ag));
+        p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma2, i), beta), bg));
+        p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma3, i), beta), cg));
+        const X p3 = fx_mul<P>(fx_mul<P>(fx_sub<P, 1>(z1, one), l1), arg_fx<P>(q.alpha2));
+        acc = fx_add<P>(acc, fx_add<P>(fx_sub<P, 2>(p1, p2), p3));               // < 16p
+    }
+    {   // keys/lookup.rs:81-122
+        const X eps = arg_fx<P>(q.epsilon), eopd = arg_fx<P>(q.eopd);
+        const X z2 = LD(q.z2, i), z2n = LD(q.z2, j);
+        const X t = LD(q.t, i), tn = LD(q.t, j), h1 = LD(q.h1, i), h1n = LD(q.h1, j), h2 = LD(q.h2, i);
+        X k1 = fx_mul<P>(z2, arg_fx<P>(q.alpha3_opd_k2));
+        k1 = fx_mul<P>(k1, fx_add<P>(eps, fx_mul<P>(c, LD(q.q_lookup, i))));
+        k1 = fx_mul<P>(k1, fx_add<P>(fx_add<P>(eopd, t), fx_mul<P>(tn, delta)));
+        X k2 = fx_mul<P>(z2n, arg_fx<P>(q.alpha3_k2));
+        k2 = fx_mul<P>(k2, fx_add<P>(fx_add<P>(eopd, h1), fx_mul<P>(h2, delta)));
+        k2 = fx_mul<P>(k2, fx_add<P>(fx_add<P>(eopd, h2), fx_mul<P>(h1n, delta)));
+        const X k3 = fx_mul<P>(fx_mul<P>(fx_sub<P, 1>(z2, one), l1), arg_fx<P>(q.alpha4));
+        const X k4 = fx_mul<P>(fx_mul<P>(t, LD(q.q_table, i)), arg_fx<P>(q.alpha5));
+        acc = fx_add<P>(acc, fx_add<P>(fx_add<P>(fx_sub<P, 2>(k1, k2), k3), k4));   // < 24p
     }
 #undef LD
     // quotient_poly.rs:220-224: times zh_coset[i]^-1; x^n - 1 takes 4 values on the 4n coset
-    Fe<P> zi = arg_fe<P>(q.zh_inv[i & 3]);
-    fe_store<P>((Fe<P>*)q.out + i, fe_mul<P>(acc, zi));
+    const X r = fx_mul<P>(acc, arg_fx<P>(q.zh_inv[i & 3]));
+    fe_store<P>((Fe<P>*)q.out + i, fx_pack<P>(fx_cond_sub_p<P>(r)));
+}
+
+// v[i] (A form) -> v[i] * 2^(5 + 5 k32) (H form times 32^k32), canonical packed
+template <class P, int K32>
+__global__ void k_to_hat(Fe<P>* v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int L = FxP<P>::L;
+    constexpr Words<P::N> w = pow2_mod<P>(2 * 29 * L - 32 * P::N + 5 * K32);
+    Fx<P> k;
+#pragma unroll
+    for (int e = 0; e < L; ++e) k.l[e] = FxP<P>::limb_of(w, e);
+    fe_store<P>(v + i, fx_pack<P>(fx_cond_sub_p<P>(fx_mul<P>(fx_unpack<P>(fe_load<P>(v + i)), k))));
 }
 
 // prove.rs:287-300 after the three chunks were copied out and trimmed (lens[0..2]); lens[3] = len(q)
@@ -539,12 +576,53 @@ template <class P> static int z_combine_t(zkt_ctx* c, const void* pn, const void
 }
 int z_combine(zkt_ctx* c, const void* pn, const void* sd, const uint32_t inv_total[8], void* out, size_t n) { ZKT_DISPATCH(c, z_combine_t, pn, sd, inv_total, out, n); }
 
+template <class P> static FxArg hat_arg(const Fe<P>& s) {   // A form -> canonical H-form limbs
+    const Fx<P> h = fx_cond_sub_p<P>(fx_from_ark<P>(s));
+    FxArg r;
+    for (int i = 0; i < 9; ++i) r.l[i] = h.l[i];
+    return r;
+}
+template <class P> static FxArg ark_arg(const Fe<P>& s) {
+    const Fx<P> h = fx_unpack<P>(s);
+    FxArg r;
+    for (int i = 0; i < 9; ++i) r.l[i] = h.l[i];
+    return r;
+}
 template <class P> static int quotient_t(zkt_ctx* c, const QuotientArgs& a) {
     ProfScope prof(c, "quotient");
-    hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(a.n4)), dim3(256), 0, c->stream, a);
+    auto get = [](const uint32_t* w) { Fe<P> r; for (int i = 0; i < 8; ++i) r.v[i] = w[i]; return r; };
+    const Fe<P> alpha = get(a.alpha), beta = get(a.beta), gamma = get(a.gamma), delta = get(a.delta), eps = get(a.epsilon);
+    const Fe<P> k2 = fe_from_u32<P>(1u << 10), k3 = fe_from_u32<P>(1u << 15);
+    const Fe<P> a2 = fe_sqr<P>(alpha), a3 = fe_mul<P>(a2, alpha), a4 = fe_mul<P>(a3, alpha), a5 = fe_mul<P>(a4, alpha);
+    const Fe<P> opd = fe_add<P>(delta, fe_one<P>());
+    QuotientDev q{};
+    q.a = a.a; q.b = a.b; q.c = a.c; q.pi = a.pi; q.z1 = a.z1; q.z2 = a.z2; q.t = a.t; q.h1 = a.h1; q.h2 = a.h2;
+    q.q_m = a.q_m; q.q_l = a.q_l; q.q_r = a.q_r; q.q_o = a.q_o; q.q_c = a.q_c; q.q_lookup = a.q_lookup; q.q_table = a.q_table;
+    q.sigma1 = a.sigma1; q.sigma2 = a.sigma2; q.sigma3 = a.sigma3; q.x = a.x; q.l1 = a.l1; q.out = a.out;
+    q.beta = hat_arg<P>(beta);
+    q.delta = hat_arg<P>(delta);
+    q.alpha_k3 = hat_arg<P>(fe_mul<P>(alpha, k3));
+    q.alpha2 = hat_arg<P>(a2);
+    q.alpha3_opd_k2 = hat_arg<P>(fe_mul<P>(fe_mul<P>(a3, opd), k2));
+    q.alpha3_k2 = hat_arg<P>(fe_mul<P>(a3, k2));
+    q.alpha4 = hat_arg<P>(a4);
+    q.alpha5 = hat_arg<P>(a5);
+    q.gamma = ark_arg<P>(gamma);
+    q.epsilon = ark_arg<P>(eps);
+    q.eopd = ark_arg<P>(fe_mul<P>(eps, opd));
+    for (int k = 0; k < 4; ++k) q.zh_inv[k] = hat_arg<P>(get(a.zh_inv[k]));
+    q.n4 = a.n4;
+    hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(a.n4)), dim3(256), 0, c->stream, q);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
+template <class P> static int to_hat_t(zkt_ctx* c, void* v, size_t n, int k32) {
+    if (k32 == 0) hipLaunchKernelGGL((k_to_hat<P, 0>), dim3(nblocks(n)), dim3(256), 0, c->stream, (Fe<P>*)v, n);
+    else hipLaunchKernelGGL((k_to_hat<P, 1>), dim3(nblocks(n)), dim3(256), 0, c->stream, (Fe<P>*)v, n);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+int to_hat_form(zkt_ctx* c, void* v, size_t n, int k32) { ZKT_DISPATCH(c, to_hat_t, v, n, k32); }
 int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a) { ZKT_DISPATCH(c, quotient_t, a); }
 
 template <class P> static int quot_split_t(zkt_ctx* c, const void* q, size_t n, const void* b0b1, void* lo, void* mid, void* hi, uint32_t* d_status) {

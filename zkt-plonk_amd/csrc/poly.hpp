@@ -53,6 +53,9 @@ int scan_add(zkt_ctx* c, const void* in, void* out, size_t n, bool reverse, void
 int z_combine(zkt_ctx* c, const void* pn, const void* sd, const uint32_t inv_total[8], void* out, size_t n);
 // quotient (quotient_poly.rs:98-224)
 int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a);
+// in place: arkworks Montgomery form -> the quotient kernel's R' = 2^261 form times 32^k32 (k32 in {0, 1}).
+// quotient_pointwise expects q_l q_r q_o q_lookup q_table l1 with k32 = 0 and q_m with k32 = 1.
+int to_hat_form(zkt_ctx* c, void* v, size_t n, int k32);
 int quotient_split_blind(zkt_ctx* c, const void* q, size_t n, const void* d_b0b1, void* q_lo, void* q_mid, void* q_hi,
                          uint32_t* d_status);                                                   // prove.rs:287-300
 // KZG opening witness: w = p / (X - z)  (kzg10::compute_witness_polynomial)

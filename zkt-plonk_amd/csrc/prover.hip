@@ -631,6 +631,10 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
         if ((rc = gen_powers(c, S.ev[0], n, one.v, ninv.v))) return rc;
         if ((rc = ntt_run(c, log_n + 2, 0, 1, S.ev[0], n, S.coset[CS_L1]))) return rc;
     }
+    // the tables that only ever multiply go to the quotient kernel's own Montgomery radix (poly.hpp)
+    if ((rc = to_hat_form(c, S.coset[CS_QM], 4 * n, 1))) return rc;
+    for (int k : {CS_QL, CS_QR, CS_QO, CS_QLOOKUP, CS_QTABLE, CS_L1})
+        if ((rc = to_hat_form(c, S.coset[k], 4 * n, 0))) return rc;
     {   // zh_coset takes four values: (g * w4n^i)^n - 1 = g^n * w4^(i mod 4) - 1   (keys/mod.rs:115-117)
         const F gn = fe_pow_u64<R>(g, (uint64_t)n);
         const F w4 = fe_pow_u64<R>(w4n, (uint64_t)n);
