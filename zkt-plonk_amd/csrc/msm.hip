@@ -20,7 +20,6 @@
 #include "ec.hpp"
 #include "ecx.hpp"
 
-#include <hipcub/hipcub.hpp>
 #include <cstring>
 
 namespace zkt {
@@ -51,9 +50,11 @@ struct MsmState {
     uint32_t B = 0;        // buckets = 2^(c-1), ids 1..B
     void* table = nullptr; // Affine[W][count]
     // work buffers (sized for n = count)
-    uint32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr;
-    void* cub_tmp = nullptr;
-    size_t cub_bytes = 0;
+    uint32_t *keys2 = nullptr, *vals2 = nullptr;   // pairs grouped by bucket
+    void* pairs = nullptr;                         // uint2[m]: after the level-1 split
+    uint32_t* bin_offs = nullptr;                  // [nb1][blocks] level-1 counts, scanned per 4096-tile
+    uint32_t* bin_aux = nullptr;                   // tile totals, scanned; last = number of pairs
+    uint32_t nb1 = 0;                              // level-1 bins
     uint32_t* offsets = nullptr;  // B + 2
     void* pieces = nullptr;       // Xyzz[max_chunks + B + 2]
     // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
@@ -134,19 +135,14 @@ __global__ void k_srs_windows(Affine<typename C::Fq>* table, size_t count, MsmWi
 // ---------------------------------------------------------------------------------------------
 // digits
 // ---------------------------------------------------------------------------------------------
-template <class C>
-__global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mont, MsmWindows win, size_t count,
-                             size_t base_off, uint32_t* keys, uint32_t* vals) {
+// signed digits of one scalar: emit(w, d, neg) with d in [0, 2^(width[w]-1)], d = 0 meaning "no contribution"
+template <class R, class F>
+ZKT_D void msm_for_each_digit(const Fe<R>& s, const MsmWindows& win, F&& emit) {
     const int W = win.W;
-    using R = typename C::Fr;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fe<R> s = fe_load<R>(scalars + i);
-    if (mont) s = fe_from_mont<R>(s);
     uint64_t buf = 0;
     int bits = 0, w = 0;
     uint32_t carry = 0;
-    auto emit = [&](uint32_t raw, int c) {
+    auto one = [&](uint32_t raw, int c) {
         const uint32_t half = 1u << (c - 1);
         uint32_t d = raw + carry, neg = 0;
         if (d > half) {
@@ -156,8 +152,7 @@ __global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mo
         } else {
             carry = 0u;
         }
-        keys[(size_t)w * n + i] = d;  // 0 = no contribution (bucket 0 is skipped)
-        vals[(size_t)w * n + i] = (uint32_t)((size_t)w * count + base_off + i) | (neg << 31);
+        emit(w, d, neg);
         ++w;
     };
 #pragma unroll
@@ -166,28 +161,168 @@ __global__ void k_msm_digits(const Fe<typename C::Fr>* scalars, size_t n, int mo
         bits += 32;
         while (w < W && bits >= (int)win.width[w]) {
             const int c = win.width[w];
-            emit((uint32_t)buf & ((1u << c) - 1u), c);
+            one((uint32_t)buf & ((1u << c) - 1u), c);
             buf >>= c;
             bits -= c;
         }
     }
     while (w < W) {
         const int c = win.width[w];
-        emit((uint32_t)buf & ((1u << c) - 1u), c);
+        one((uint32_t)buf & ((1u << c) - 1u), c);
         buf >>= c;
     }
 }
 
-// offsets[b] = first sorted position with key >= b, b in [0, B+1]
-__global__ void k_msm_offsets(const uint32_t* keys, uint32_t m, uint32_t B, uint32_t* offsets) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > B + 1) return;
-    uint32_t lo = 0, hi = m;
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < b) lo = mid + 1; else hi = mid;
+// ---------------------------------------------------------------------------------------------
+// grouping the (bucket, table index) pairs by bucket: a two-level counting sort made for this key
+// shape (at most 18 key bits, roughly uniform).  Level 1 splits on key >> 8 straight from the scalars
+// (count, scan, scatter: the digits are recomputed instead of stored), level 2 finishes each of the
+// <= 513 bins inside one workgroup and emits the bucket offsets on the way.  Order inside a bucket
+// is arbitrary, which is all the accumulation needs.  Zero digits are dropped here.
+// ---------------------------------------------------------------------------------------------
+constexpr int MSM_BIN_LB = 8;         // level-2 key bits
+constexpr int MSM_BIN_TILE = 4;       // scalars per thread in the level-1 kernels
+constexpr int MSM_BIN_SCALARS = 256 * MSM_BIN_TILE;
+
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_bin_count(const Fe<typename C::Fr>* scalars, size_t n, int mont,
+                                                       MsmWindows win, uint32_t nb1, uint32_t* counts) {
+    using R = typename C::Fr;
+    extern __shared__ uint32_t hist[];
+    for (uint32_t b = threadIdx.x; b < nb1; b += 256) hist[b] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int e = 0; e < MSM_BIN_TILE; ++e) {
+        const size_t i = ((size_t)blockIdx.x * MSM_BIN_TILE + e) * 256 + threadIdx.x;
+        if (i >= n) break;
+        Fe<R> s = fe_load<R>(scalars + i);
+        if (mont) s = fe_from_mont<R>(s);
+        msm_for_each_digit<R>(s, win, [&](int, uint32_t d, uint32_t) {
+            if (d) atomicAdd(&hist[d >> MSM_BIN_LB], 1u);
+        });
     }
-    offsets[b] = lo;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb1; b += 256) counts[(size_t)b * gridDim.x + blockIdx.x] = hist[b];
+}
+
+// exclusive scan of the level-1 counts in two small launches: 4096-element tiles scanned in place, then the
+// tile totals (aux).  Readers add the two parts themselves: off(i) = counts[i] + aux[i >> 12].
+constexpr int MSM_SCAN_TILE = 4096;
+__global__ __launch_bounds__(1024) void k_msm_scan_tiles(uint32_t* counts, uint32_t total, uint32_t* aux) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t i0 = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < total) ? counts[i0 + k] : 0u;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < total) counts[i0 + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 1023) aux[blockIdx.x] = run;
+}
+// aux[0 .. nt) -> exclusive, aux[nt] = grand total.  One workgroup.
+__global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t nt) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nt; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t mine = (i < nt) ? aux[i] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+        if (i < nt) aux[i] = before + incl - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) aux[nt] = carry;
+}
+ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, size_t total) {
+    return (i < total) ? offs[i] + aux[i / MSM_SCAN_TILE] : aux[(total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE];
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_bin_scatter(const Fe<typename C::Fr>* scalars, size_t n, int mont,
+                                                         MsmWindows win, size_t count, size_t base_off, uint32_t nb1,
+                                                         const uint32_t* offs, const uint32_t* aux, uint2* pairs) {
+    using R = typename C::Fr;
+    extern __shared__ uint32_t pos[];
+    const size_t total = (size_t)nb1 * gridDim.x;
+    for (uint32_t b = threadIdx.x; b < nb1; b += 256)
+        pos[b] = msm_bin_off(offs, aux, (size_t)b * gridDim.x + blockIdx.x, total);
+    __syncthreads();
+#pragma unroll 1
+    for (int e = 0; e < MSM_BIN_TILE; ++e) {
+        const size_t i = ((size_t)blockIdx.x * MSM_BIN_TILE + e) * 256 + threadIdx.x;
+        if (i >= n) break;
+        Fe<R> s = fe_load<R>(scalars + i);
+        if (mont) s = fe_from_mont<R>(s);
+        msm_for_each_digit<R>(s, win, [&](int w, uint32_t d, uint32_t neg) {
+            if (d) {
+                const uint32_t at = atomicAdd(&pos[d >> MSM_BIN_LB], 1u);
+                pairs[at] = make_uint2(d, (uint32_t)((size_t)w * count + base_off + i) | (neg << 31));
+            }
+        });
+    }
+}
+
+// level 2: workgroup b orders bin b (keys b*256 .. b*256+255) and writes offsets[key] for its keys;
+// offsets[B + 1] (= number of pairs) falls out of the last bin because no key exceeds B.
+__global__ __launch_bounds__(1024) void k_msm_bin_sort(const uint2* pairs, const uint32_t* offs, const uint32_t* aux,
+                                                       uint32_t nblk, uint32_t B, uint32_t* keys, uint32_t* vals,
+                                                       uint32_t* offsets) {
+    __shared__ uint32_t cnt[256], start[256];
+    const uint32_t b = blockIdx.x;
+    const size_t total = (size_t)gridDim.x * nblk;
+    const uint32_t s = msm_bin_off(offs, aux, (size_t)b * nblk, total), e = msm_bin_off(offs, aux, (size_t)(b + 1) * nblk, total);
+    if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t p = s + threadIdx.x; p < e; p += 1024) atomicAdd(&cnt[pairs[p].x & 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 256) start[threadIdx.x] = cnt[threadIdx.x];
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint32_t v = 0;
+        if (threadIdx.x < 256 && threadIdx.x >= (uint32_t)d) v = start[threadIdx.x - d];
+        __syncthreads();
+        if (threadIdx.x < 256) start[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x < 256) {
+        const uint32_t first = s + start[threadIdx.x] - cnt[threadIdx.x];
+        const uint32_t key = b * 256u + threadIdx.x;
+        if (key <= B + 1) offsets[key] = first;
+        start[threadIdx.x] = first;
+    }
+    __syncthreads();
+    for (uint32_t p = s + threadIdx.x; p < e; p += 1024) {
+        const uint2 kv = pairs[p];
+        const uint32_t at = atomicAdd(&start[kv.x & 255u], 1u);
+        keys[at] = kv.x;
+        vals[at] = kv.y;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,12 +331,12 @@ __global__ void k_msm_offsets(const uint32_t* keys, uint32_t m, uint32_t B, uint
 // are canonical packed words in R' Montgomery form.
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t m,
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t B,
                                                         uint32_t chunk, const uint32_t* offsets,
                                                         const Affine<typename C::Fq>* table,
                                                         Xyzz<typename C::Fq>* pieces) {
     using Q = typename C::Fq;
-    const uint32_t base = offsets[1];
+    const uint32_t base = offsets[1], m = offsets[B + 1];   // first / one past the last pair with a non-zero bucket
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p0 = (uint64_t)base + (uint64_t)t * chunk;
     if (p0 >= m) return;
@@ -437,14 +572,13 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     int rc;
     if ((rc = dev_alloc(c, &st->table, (size_t)st->W * count * sizeof(Affine<Q>)))) return rc;
     size_t m = (size_t)st->W * count;
-    if ((rc = dev_alloc(c, (void**)&st->keys, m * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->keys2, m * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->vals, m * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->vals2, m * 4))) return rc;
-    st->cub_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, st->cub_bytes, st->keys, st->keys2, st->vals, st->vals2, (int)m, 0,
-                                       st->c, c->stream);
-    if ((rc = dev_alloc(c, &st->cub_tmp, st->cub_bytes + 256))) return rc;
+    if ((rc = dev_alloc(c, &st->pairs, m * 8))) return rc;
+    st->nb1 = (st->B >> MSM_BIN_LB) + 1;
+    const size_t max_blk = (count + MSM_BIN_SCALARS - 1) / MSM_BIN_SCALARS;
+    if ((rc = dev_alloc(c, (void**)&st->bin_offs, ((size_t)st->nb1 * max_blk + 1) * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->bin_aux, ((size_t)st->nb1 * max_blk / MSM_SCAN_TILE + 4) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->B + 2) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
     size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
@@ -493,7 +627,7 @@ static void msm_release(zkt_ctx* c) {
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
-    void* ptrs[] = {st.heavy, st.table, st.keys, st.keys2, st.vals, st.vals2, st.cub_tmp, st.offsets, st.pieces};
+    void* ptrs[] = {st.heavy, st.table, st.keys2, st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.offsets, st.pieces};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
@@ -572,22 +706,28 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     {
     ProfScope prof_all(c, "msm_main");
     {
-        unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_msm_digits<C>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<R>*)d_scalars, n, mont,
-                           st.win, st.count, base_off, st.keys, st.vals);
+        ProfScope prof_sort(c, "msm_group");
+        const unsigned nblk = (unsigned)((n + MSM_BIN_SCALARS - 1) / MSM_BIN_SCALARS);
+        const size_t lds = (size_t)st.nb1 * 4;
+        hipLaunchKernelGGL(k_msm_bin_count<C>, dim3(nblk), dim3(256), lds, c->stream, (const Fe<R>*)d_scalars, n, mont,
+                           st.win, st.nb1, st.bin_offs);
+        ZKT_HIP(c, hipGetLastError());
+        const uint32_t total = st.nb1 * nblk, ntiles = (total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
+        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_aux, ntiles);
+        ZKT_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(256), lds, c->stream, (const Fe<R>*)d_scalars, n,
+                           mont, st.win, st.count, base_off, st.nb1, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+        ZKT_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k_msm_bin_sort, dim3(st.nb1), dim3(1024), 0, c->stream, (const uint2*)st.pairs, st.bin_offs,
+                           st.bin_aux, nblk, st.B, st.keys2, st.vals2, st.offsets);
         ZKT_HIP(c, hipGetLastError());
     }
-    size_t tmp = st.cub_bytes;
-    ZKT_HIP(c, hipcub::DeviceRadixSort::SortPairs(st.cub_tmp, tmp, st.keys, st.keys2, st.vals, st.vals2, (int)m, 0,
-                                                  st.c, c->stream));
-    hipLaunchKernelGGL(k_msm_offsets, dim3((st.B + 2 + 255) / 256), dim3(256), 0, c->stream, st.keys2, m, st.B,
-                       st.offsets);
-    ZKT_HIP(c, hipGetLastError());
     {
         ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + chunk - 1) / chunk;
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.keys2,
-                           st.vals2, m, chunk, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
+                           st.vals2, st.B, chunk, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
     // the slot's tail buffers may still be read by the previous MSM that used this slot
