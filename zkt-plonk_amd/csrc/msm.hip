@@ -50,11 +50,15 @@ struct MsmState {
     uint32_t B = 0;        // buckets = 2^(c-1), ids 1..B
     void* table = nullptr; // Affine[W][count]
     // work buffers (sized for n = count)
-    uint32_t *keys2 = nullptr, *vals2 = nullptr;   // pairs grouped by bucket
+    uint32_t* vals2 = nullptr;                     // table indices grouped by bucket
     void* pairs = nullptr;                         // uint2[m]: after the level-1 split
     uint32_t* bin_offs = nullptr;                  // [nb1][blocks] level-1 counts, scanned per 4096-tile
     uint32_t* bin_aux = nullptr;                   // tile totals, scanned; last = number of pairs
+    uint32_t *bin_start = nullptr, *tile_start = nullptr;   // nb1 + 1 each: level-2 work list
+    uint32_t *cnt2 = nullptr, *pos2 = nullptr;     // [level-2 tiles][256]
     uint32_t nb1 = 0;                              // level-1 bins
+    uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
+    uint32_t l2_items = 0;                         // upper bound of level-2 tiles
     uint32_t* offsets = nullptr;  // B + 2
     void* pieces = nullptr;       // Xyzz[max_chunks + B + 2]
     // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
@@ -175,26 +179,51 @@ ZKT_D void msm_for_each_digit(const Fe<R>& s, const MsmWindows& win, F&& emit) {
 
 // ---------------------------------------------------------------------------------------------
 // grouping the (bucket, table index) pairs by bucket: a two-level counting sort made for this key
-// shape (at most 18 key bits, roughly uniform).  Level 1 splits on key >> 8 straight from the scalars
-// (count, scan, scatter: the digits are recomputed instead of stored), level 2 finishes each of the
-// <= 513 bins inside one workgroup and emits the bucket offsets on the way.  Order inside a bucket
-// is arbitrary, which is all the accumulation needs.  Zero digits are dropped here.
+// shape (at most 18 key bits, roughly uniform digits) instead of a general radix sort.
+//   level 1  splits on key >> 8 straight from the scalars: count, scan, scatter.  The digits are
+//            recomputed rather than stored, and each workgroup orders its pairs in LDS first so that
+//            the global writes are runs, not single pairs.
+//   level 2  finishes every bin (256 buckets) in tiles of 8192 pairs: count, scan, scatter again,
+//            the last one writing only the table indices plus offsets[bucket].
+// Order inside a bucket is arbitrary, which is all the accumulation needs.  Zero digits are dropped.
 // ---------------------------------------------------------------------------------------------
-constexpr int MSM_BIN_LB = 8;         // level-2 key bits
-constexpr int MSM_BIN_TILE = 4;       // scalars per thread in the level-1 kernels
-constexpr int MSM_BIN_SCALARS = 256 * MSM_BIN_TILE;
+constexpr int MSM_BIN_LB = 8;             // level-2 key bits
+constexpr int MSM_L1_CAP = 15360;         // pairs staged per level-1 workgroup (120 KB of LDS)
+constexpr int MSM_L2_TILE = 8192;         // pairs per level-2 workgroup
+constexpr int MSM_MAX_NB1 = 1024;         // level-1 bins (one per thread in the scans below)
+
+// exclusive scan of one value per thread over a 1024-thread workgroup; `wsum`: 16 LDS words
+ZKT_D uint32_t block_excl_scan_1024(uint32_t mine, uint32_t* wsum, uint32_t* total) {
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    __syncthreads();   // wsum may still be read from a previous call
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+        const uint32_t v = wsum[w];
+        if (w < (threadIdx.x >> 6)) before += v;
+        all += v;
+    }
+    if (total) *total = all;
+    return before + incl - mine;
+}
 
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_bin_count(const Fe<typename C::Fr>* scalars, size_t n, int mont,
-                                                       MsmWindows win, uint32_t nb1, uint32_t* counts) {
+__global__ __launch_bounds__(1024) void k_msm_bin_count(const Fe<typename C::Fr>* scalars, size_t n, int mont,
+                                                        MsmWindows win, uint32_t per_block, uint32_t nb1,
+                                                        uint32_t* counts) {
     using R = typename C::Fr;
-    extern __shared__ uint32_t hist[];
-    for (uint32_t b = threadIdx.x; b < nb1; b += 256) hist[b] = 0;
+    extern __shared__ uint32_t lds[];
+    uint32_t* hist = lds;
+    for (uint32_t b = threadIdx.x; b < nb1; b += 1024) hist[b] = 0;
     __syncthreads();
-#pragma unroll 1
-    for (int e = 0; e < MSM_BIN_TILE; ++e) {
-        const size_t i = ((size_t)blockIdx.x * MSM_BIN_TILE + e) * 256 + threadIdx.x;
-        if (i >= n) break;
+    const size_t i = (size_t)blockIdx.x * per_block + threadIdx.x;
+    if (threadIdx.x < per_block && i < n) {
         Fe<R> s = fe_load<R>(scalars + i);
         if (mont) s = fe_from_mont<R>(s);
         msm_for_each_digit<R>(s, win, [&](int, uint32_t d, uint32_t) {
@@ -202,7 +231,7 @@ __global__ __launch_bounds__(256) void k_msm_bin_count(const Fe<typename C::Fr>*
         });
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb1; b += 256) counts[(size_t)b * gridDim.x + blockIdx.x] = hist[b];
+    for (uint32_t b = threadIdx.x; b < nb1; b += 1024) counts[(size_t)b * gridDim.x + blockIdx.x] = hist[b];
 }
 
 // exclusive scan of the level-1 counts in two small launches: 4096-element tiles scanned in place, then the
@@ -215,47 +244,26 @@ __global__ __launch_bounds__(1024) void k_msm_scan_tiles(uint32_t* counts, uint3
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = (i0 + k < total) ? counts[i0 + k] : 0u;
     const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if ((int)(threadIdx.x & 63) >= d) incl += o;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
-    uint32_t run = before + incl - mine;
+    uint32_t all;
+    uint32_t run = block_excl_scan_1024(mine, wsum, &all);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (i0 + k < total) counts[i0 + k] = run;
         run += v[k];
     }
-    if (threadIdx.x == 1023) aux[blockIdx.x] = run;
+    if (threadIdx.x == 0) aux[blockIdx.x] = all;
 }
 // aux[0 .. nt) -> exclusive, aux[nt] = grand total.  One workgroup.
 __global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t nt) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    uint32_t carry = 0;
     for (uint32_t base = 0; base < nt; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t mine = (i < nt) ? aux[i] : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if ((int)(threadIdx.x & 63) >= d) incl += o;
-        }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint32_t before = carry;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
-        if (i < nt) aux[i] = before + incl - mine;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + incl;
-        __syncthreads();
+        uint32_t all;
+        const uint32_t ex = block_excl_scan_1024(mine, wsum, &all);
+        if (i < nt) aux[i] = carry + ex;
+        carry += all;
     }
     if (threadIdx.x == 0) aux[nt] = carry;
 }
@@ -263,66 +271,162 @@ ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, 
     return (i < total) ? offs[i] + aux[i / MSM_SCAN_TILE] : aux[(total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE];
 }
 
+// LDS: cursor[nb1] | delta[nb1] | stage uint2[MSM_L1_CAP]
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_bin_scatter(const Fe<typename C::Fr>* scalars, size_t n, int mont,
-                                                         MsmWindows win, size_t count, size_t base_off, uint32_t nb1,
-                                                         const uint32_t* offs, const uint32_t* aux, uint2* pairs) {
+__global__ __launch_bounds__(1024) void k_msm_bin_scatter(const Fe<typename C::Fr>* scalars, size_t n, int mont,
+                                                          MsmWindows win, uint32_t per_block, size_t count,
+                                                          size_t base_off, uint32_t nb1, const uint32_t* offs,
+                                                          const uint32_t* aux, uint2* pairs) {
     using R = typename C::Fr;
-    extern __shared__ uint32_t pos[];
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t wsum[16];
+    uint32_t* cursor = lds;
+    uint32_t* delta = lds + nb1;
+    uint2* stage = (uint2*)(lds + 2 * nb1);
     const size_t total = (size_t)nb1 * gridDim.x;
-    for (uint32_t b = threadIdx.x; b < nb1; b += 256)
-        pos[b] = msm_bin_off(offs, aux, (size_t)b * gridDim.x + blockIdx.x, total);
+    // this workgroup's level-1 histogram is the difference of neighbouring scanned counts
+    uint32_t g0 = 0, mine = 0;
+    if (threadIdx.x < nb1) {
+        const size_t at = (size_t)threadIdx.x * gridDim.x + blockIdx.x;
+        g0 = msm_bin_off(offs, aux, at, total);
+        mine = msm_bin_off(offs, aux, at + 1, total) - g0;
+    }
+    uint32_t staged;
+    const uint32_t ex = block_excl_scan_1024(mine, wsum, &staged);
+    if (threadIdx.x < nb1) {
+        cursor[threadIdx.x] = ex;
+        delta[threadIdx.x] = g0 - ex;
+    }
     __syncthreads();
-#pragma unroll 1
-    for (int e = 0; e < MSM_BIN_TILE; ++e) {
-        const size_t i = ((size_t)blockIdx.x * MSM_BIN_TILE + e) * 256 + threadIdx.x;
-        if (i >= n) break;
+    const size_t i = (size_t)blockIdx.x * per_block + threadIdx.x;
+    if (threadIdx.x < per_block && i < n) {
         Fe<R> s = fe_load<R>(scalars + i);
         if (mont) s = fe_from_mont<R>(s);
         msm_for_each_digit<R>(s, win, [&](int w, uint32_t d, uint32_t neg) {
             if (d) {
-                const uint32_t at = atomicAdd(&pos[d >> MSM_BIN_LB], 1u);
-                pairs[at] = make_uint2(d, (uint32_t)((size_t)w * count + base_off + i) | (neg << 31));
+                const uint32_t at = atomicAdd(&cursor[d >> MSM_BIN_LB], 1u);
+                stage[at] = make_uint2(d, (uint32_t)((size_t)w * count + base_off + i) | (neg << 31));
             }
         });
     }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < staged; j += 1024) {
+        const uint2 kv = stage[j];
+        pairs[delta[kv.x >> MSM_BIN_LB] + j] = kv;
+    }
 }
 
-// level 2: workgroup b orders bin b (keys b*256 .. b*256+255) and writes offsets[key] for its keys;
-// offsets[B + 1] (= number of pairs) falls out of the last bin because no key exceeds B.
-__global__ __launch_bounds__(1024) void k_msm_bin_sort(const uint2* pairs, const uint32_t* offs, const uint32_t* aux,
-                                                       uint32_t nblk, uint32_t B, uint32_t* keys, uint32_t* vals,
-                                                       uint32_t* offsets) {
-    __shared__ uint32_t cnt[256], start[256];
+// level-2 work list: bin b owns tiles [tile_start[b], tile_start[b + 1]) of MSM_L2_TILE pairs each
+__global__ __launch_bounds__(1024) void k_msm_l2_plan(const uint32_t* offs, const uint32_t* aux, uint32_t nblk,
+                                                      uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start) {
+    __shared__ uint32_t wsum[16];
+    const size_t total = (size_t)nb1 * nblk;
+    uint32_t s = 0, tiles = 0;
+    if (threadIdx.x <= nb1) s = msm_bin_off(offs, aux, (size_t)threadIdx.x * nblk, total);
+    if (threadIdx.x < nb1) {
+        const uint32_t e = msm_bin_off(offs, aux, (size_t)(threadIdx.x + 1) * nblk, total);
+        tiles = (e - s + MSM_L2_TILE - 1) / MSM_L2_TILE;
+    }
+    uint32_t all;
+    const uint32_t ex = block_excl_scan_1024(tiles, wsum, &all);
+    if (threadIdx.x <= nb1) {
+        bin_start[threadIdx.x] = s;
+        tile_start[threadIdx.x] = ex;   // thread nb1 contributes 0 tiles, so this is the grand total there
+    }
+}
+
+struct L2Item {
+    uint32_t bin, s, e;
+    bool valid;
+};
+ZKT_D L2Item msm_l2_item(uint32_t item, uint32_t nb1, const uint32_t* bin_start, const uint32_t* tile_start) {
+    L2Item r;
+    r.valid = item < tile_start[nb1];
+    r.bin = 0; r.s = 0; r.e = 0;
+    if (!r.valid) return r;
+    uint32_t lo = 0, hi = nb1 - 1;          // last bin with tile_start[bin] <= item
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= item) lo = mid; else hi = mid - 1;
+    }
+    r.bin = lo;
+    const uint32_t sub = item - tile_start[lo];
+    r.s = bin_start[lo] + sub * MSM_L2_TILE;
+    const uint32_t be = bin_start[lo + 1];
+    r.e = (r.s + MSM_L2_TILE < be) ? r.s + MSM_L2_TILE : be;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_msm_l2_count(const uint2* pairs, uint32_t nb1, const uint32_t* bin_start,
+                                                      const uint32_t* tile_start, uint32_t* cnt2) {
+    __shared__ uint32_t hist[256];
+    const L2Item it = msm_l2_item(blockIdx.x, nb1, bin_start, tile_start);
+    if (!it.valid) return;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t p = it.s + threadIdx.x; p < it.e; p += 256) atomicAdd(&hist[pairs[p].x & 255u], 1u);
+    __syncthreads();
+    cnt2[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+// one workgroup per bin: positions of every (tile, bucket) run and offsets[bucket]
+__global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint32_t* pos2, const uint32_t* bin_start,
+                                                     const uint32_t* tile_start, uint32_t* offsets) {
+    __shared__ uint32_t tot[256];
     const uint32_t b = blockIdx.x;
-    const size_t total = (size_t)gridDim.x * nblk;
-    const uint32_t s = msm_bin_off(offs, aux, (size_t)b * nblk, total), e = msm_bin_off(offs, aux, (size_t)(b + 1) * nblk, total);
-    if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t p = s + threadIdx.x; p < e; p += 1024) atomicAdd(&cnt[pairs[p].x & 255u], 1u);
-    __syncthreads();
-    if (threadIdx.x < 256) start[threadIdx.x] = cnt[threadIdx.x];
+    const uint32_t t0 = tile_start[b], t1 = tile_start[b + 1];
+    uint32_t run = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const size_t at = (size_t)t * 256 + threadIdx.x;
+        pos2[at] = run;
+        run += cnt2[at];
+    }
+    tot[threadIdx.x] = run;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
-        uint32_t v = 0;
-        if (threadIdx.x < 256 && threadIdx.x >= (uint32_t)d) v = start[threadIdx.x - d];
+        const uint32_t v = (threadIdx.x >= (uint32_t)d) ? tot[threadIdx.x - d] : 0u;
         __syncthreads();
-        if (threadIdx.x < 256) start[threadIdx.x] += v;
+        tot[threadIdx.x] += v;
         __syncthreads();
     }
-    if (threadIdx.x < 256) {
-        const uint32_t first = s + start[threadIdx.x] - cnt[threadIdx.x];
-        const uint32_t key = b * 256u + threadIdx.x;
-        if (key <= B + 1) offsets[key] = first;
-        start[threadIdx.x] = first;
+    const uint32_t first = bin_start[b] + tot[threadIdx.x] - run;
+    offsets[b * 256u + threadIdx.x] = first;   // sized nb1 * 256 + 2; keys above B are empty and repeat the end
+    for (uint32_t t = t0; t < t1; ++t) pos2[(size_t)t * 256 + threadIdx.x] += first;
+}
+
+__global__ __launch_bounds__(256) void k_msm_l2_scatter(const uint2* pairs, uint32_t nb1, const uint32_t* bin_start,
+                                                        const uint32_t* tile_start, const uint32_t* cnt2,
+                                                        const uint32_t* pos2, uint32_t* vals) {
+    __shared__ uint32_t cursor[256], delta[256];
+    __shared__ uint32_t sval[MSM_L2_TILE];
+    __shared__ uint8_t skey[MSM_L2_TILE];
+    const L2Item it = msm_l2_item(blockIdx.x, nb1, bin_start, tile_start);
+    if (!it.valid) return;
+    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mine = cnt2[at];
+    cursor[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (uint32_t)d) ? cursor[threadIdx.x - d] : 0u;
+        __syncthreads();
+        cursor[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t ex = cursor[threadIdx.x] - mine;
+    __syncthreads();
+    cursor[threadIdx.x] = ex;
+    delta[threadIdx.x] = pos2[at] - ex;
+    __syncthreads();
+    for (uint32_t p = it.s + threadIdx.x; p < it.e; p += 256) {
+        const uint2 kv = pairs[p];
+        const uint32_t low = kv.x & 255u;
+        const uint32_t a = atomicAdd(&cursor[low], 1u);
+        sval[a] = kv.y;
+        skey[a] = (uint8_t)low;
     }
     __syncthreads();
-    for (uint32_t p = s + threadIdx.x; p < e; p += 1024) {
-        const uint2 kv = pairs[p];
-        const uint32_t at = atomicAdd(&start[kv.x & 255u], 1u);
-        keys[at] = kv.x;
-        vals[at] = kv.y;
-    }
+    const uint32_t cnt = it.e - it.s;
+    for (uint32_t j = threadIdx.x; j < cnt; j += 256) vals[delta[skey[j]] + j] = sval[j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,8 +435,8 @@ __global__ __launch_bounds__(1024) void k_msm_bin_sort(const uint2* pairs, const
 // are canonical packed words in R' Montgomery form.
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t B,
-                                                        uint32_t chunk, const uint32_t* offsets,
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, uint32_t chunk,
+                                                        const uint32_t* offsets,
                                                         const Affine<typename C::Fq>* table,
                                                         Xyzz<typename C::Fq>* pieces) {
     using Q = typename C::Fq;
@@ -341,12 +445,21 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, co
     const uint64_t p0 = (uint64_t)base + (uint64_t)t * chunk;
     if (p0 >= m) return;
     const uint32_t p1 = (uint32_t)((p0 + chunk < m) ? p0 + chunk : m);
-    uint32_t cur = keys[p0];
+    // bucket of the first pair: the first b with offsets[b + 1] > p0
+    uint32_t cur;
+    {
+        uint32_t lo = 1, hi = B;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (offsets[mid + 1] <= (uint32_t)p0) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+    }
+    uint32_t end = offsets[cur + 1];
     XyzzX<Q> acc = xx_identity<Q>();
     uint32_t v = vals[p0];
     Fe<Q> nx = fe_load<Q>(&table[v & 0x7fffffffu].x), ny = fe_load<Q>(&table[v & 0x7fffffffu].y);
     for (uint32_t p = (uint32_t)p0; p < p1; ++p) {
-        const uint32_t key = keys[p];
         const uint32_t vcur = v;
         const Fe<Q> cx = nx, cy = ny;
         if (p + 1 < p1) {  // prefetch the next gathered point behind this addition
@@ -354,10 +467,13 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* keys, co
             nx = fe_load<Q>(&table[v & 0x7fffffffu].x);
             ny = fe_load<Q>(&table[v & 0x7fffffffu].y);
         }
-        if (key != cur) {
+        if (p == end) {    // next non-empty bucket
             xx_store<Q>(pieces + (size_t)t + cur, acc);
             acc = xx_identity<Q>();
-            cur = key;
+            do {
+                ++cur;
+                end = offsets[cur + 1];
+            } while (end <= p);
         }
         if (!(fe_is_zero<Q>(cx) && fe_is_zero<Q>(cy))) {
             AffineX<Q> q;
@@ -572,14 +688,25 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     int rc;
     if ((rc = dev_alloc(c, &st->table, (size_t)st->W * count * sizeof(Affine<Q>)))) return rc;
     size_t m = (size_t)st->W * count;
-    if ((rc = dev_alloc(c, (void**)&st->keys2, m * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->vals2, m * 4))) return rc;
     if ((rc = dev_alloc(c, &st->pairs, m * 8))) return rc;
     st->nb1 = (st->B >> MSM_BIN_LB) + 1;
-    const size_t max_blk = (count + MSM_BIN_SCALARS - 1) / MSM_BIN_SCALARS;
+    if (st->nb1 > (uint32_t)MSM_MAX_NB1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm: too many level-1 bins");
+    st->l1_scalars = (uint32_t)(MSM_L1_CAP / st->W) & ~63u;
+    if (st->l1_scalars > 1024) st->l1_scalars = 1024;
+    const size_t max_blk = (count + st->l1_scalars - 1) / st->l1_scalars;
     if ((rc = dev_alloc(c, (void**)&st->bin_offs, ((size_t)st->nb1 * max_blk + 1) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->bin_aux, ((size_t)st->nb1 * max_blk / MSM_SCAN_TILE + 4) * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->B + 2) * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->bin_start, ((size_t)st->nb1 + 1) * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->tile_start, ((size_t)st->nb1 + 1) * 4))) return rc;
+    st->l2_items = (uint32_t)(m / MSM_L2_TILE + st->nb1);
+    if ((rc = dev_alloc(c, (void**)&st->cnt2, (size_t)st->l2_items * 256 * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->pos2, (size_t)st->l2_items * 256 * 4))) return rc;
+    {
+        const int lds = (int)(2 * st->nb1 * 4 + MSM_L1_CAP * 8);
+        ZKT_HIP(c, hipFuncSetAttribute((const void*)k_msm_bin_scatter<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->nb1 * 256 + 2) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
     size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
     if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(Xyzz<Q>)))) return rc;
@@ -627,7 +754,8 @@ static void msm_release(zkt_ctx* c) {
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
-    void* ptrs[] = {st.heavy, st.table, st.keys2, st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.offsets, st.pieces};
+    void* ptrs[] = {st.heavy,   st.table,     st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
+                    st.tile_start, st.cnt2,   st.pos2,  st.offsets, st.pieces};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
@@ -707,27 +835,34 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     ProfScope prof_all(c, "msm_main");
     {
         ProfScope prof_sort(c, "msm_group");
-        const unsigned nblk = (unsigned)((n + MSM_BIN_SCALARS - 1) / MSM_BIN_SCALARS);
-        const size_t lds = (size_t)st.nb1 * 4;
-        hipLaunchKernelGGL(k_msm_bin_count<C>, dim3(nblk), dim3(256), lds, c->stream, (const Fe<R>*)d_scalars, n, mont,
-                           st.win, st.nb1, st.bin_offs);
-        ZKT_HIP(c, hipGetLastError());
+        const uint32_t S = st.l1_scalars;
+        const unsigned nblk = (unsigned)((n + S - 1) / S);
         const uint32_t total = st.nb1 * nblk, ntiles = (total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
+        hipLaunchKernelGGL(k_msm_bin_count<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream,
+                           (const Fe<R>*)d_scalars, n, mont, st.win, S, st.nb1, st.bin_offs);
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
         hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_aux, ntiles);
         ZKT_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(256), lds, c->stream, (const Fe<R>*)d_scalars, n,
-                           mont, st.win, st.count, base_off, st.nb1, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+        hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 8 + (size_t)MSM_L1_CAP * 8,
+                           c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S, st.count, base_off, st.nb1,
+                           st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+        hipLaunchKernelGGL(k_msm_l2_plan, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, nblk, st.nb1,
+                           st.bin_start, st.tile_start);
         ZKT_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_msm_bin_sort, dim3(st.nb1), dim3(1024), 0, c->stream, (const uint2*)st.pairs, st.bin_offs,
-                           st.bin_aux, nblk, st.B, st.keys2, st.vals2, st.offsets);
+        const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
+        hipLaunchKernelGGL(k_msm_l2_count, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+                           st.bin_start, st.tile_start, st.cnt2);
+        hipLaunchKernelGGL(k_msm_l2_scan, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
+                           st.tile_start, st.offsets);
+        hipLaunchKernelGGL(k_msm_l2_scatter, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+                           st.bin_start, st.tile_start, st.cnt2, st.pos2, st.vals2);
         ZKT_HIP(c, hipGetLastError());
     }
     {
         ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + chunk - 1) / chunk;
-        hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.keys2,
-                           st.vals2, st.B, chunk, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
+        hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.vals2,
+                           st.B, chunk, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
     // the slot's tail buffers may still be read by the previous MSM that used this slot
