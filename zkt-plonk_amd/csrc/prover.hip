@@ -286,12 +286,14 @@ struct Prover {
         Affine<Q> cm[11];
         static const char* L1[3] = {"a_commit", "b_commit", "c_commit"};
         for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
-        for (int k = 0; k < 3; ++k) {
-            if ((rc = commit_end(k, &cm[k]))) return rc;
-            tr_commit(L1[k], cm[k]);
-        }
+        // quotient_poly.rs:52-96 needs every witness polynomial on the 4n coset.  None of those transforms
+        // depends on a challenge, so each is issued right behind the commitment of its polynomial, where it
+        // hides the latency-bound tail of the last MSM of the round (which runs on the side stream).
+        const int coset_src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
+        auto to_coset = [&](int k) { return ntt_run(c, log_n + 2, 0, 1, S.poly[coset_src[k]], n + 8, S.wcos[k]); };
 
-        // ---- round 2 (prove.rs:145-185) ----
+        // ---- round 2 (prove.rs:145-185): nothing here waits for a challenge either, so its three commitments
+        // join the same batch before the transcript sees a_commit
         const bool same_table = S.t_cached && S.cached_table.size() == 4 * in.table_len &&
                                 (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
         if (!same_table) {
@@ -305,11 +307,18 @@ struct Prover {
         if ((rc = combine_split(in.table, in.table_len))) return rc;
         if ((rc = evals_to_blinded_poly(S.ev[5], S.poly[4], 6, 3, 4))) return rc;          // h1: 3 blinders
         if ((rc = evals_to_blinded_poly(S.ev[6], S.poly[5], 9, 2, 5))) return rc;          // h2: 2 blinders
-        if (!same_table && (rc = commit_begin(S.poly[3], n, 0))) return rc;
-        if ((rc = commit_begin(S.poly[4], n + 3, 1))) return rc;
-        if ((rc = commit_begin(S.poly[5], n + 2, 2))) return rc;
+        if (!same_table && (rc = commit_begin(S.poly[3], n, 3))) return rc;
+        if ((rc = commit_begin(S.poly[4], n + 3, 4))) return rc;
+        if ((rc = commit_begin(S.poly[5], n + 2, 5))) return rc;
+        for (int k : {W_A, W_B, W_C}) if ((rc = to_coset(k))) return rc;
+        if (!S.t_coset_valid && (rc = to_coset(W_T))) return rc;   // unchanged table: its coset is still resident
+        for (int k : {W_H1, W_H2}) if ((rc = to_coset(k))) return rc;
+        for (int k = 0; k < 3; ++k) {
+            if ((rc = commit_end(k, &cm[k]))) return rc;
+            tr_commit(L1[k], cm[k]);
+        }
         if (!same_table) {
-            if ((rc = commit_end(0, &cm[3]))) return rc;
+            if ((rc = commit_end(3, &cm[3]))) return rc;
             memcpy(S.t_commit_xy, cm[3].x.v, Q::N * 4);
             memcpy(S.t_commit_xy + Q::N / 2, cm[3].y.v, Q::N * 4);
             S.cached_table.assign(in.table, in.table + 4 * in.table_len);
@@ -318,7 +327,7 @@ struct Prover {
             memcpy(cm[3].x.v, S.t_commit_xy, Q::N * 4);
             memcpy(cm[3].y.v, S.t_commit_xy + Q::N / 2, Q::N * 4);
         }
-        for (int k = 1; k < 3; ++k) if ((rc = commit_end(k, &cm[3 + k]))) return rc;
+        for (int k = 1; k < 3; ++k) if ((rc = commit_end(3 + k, &cm[3 + k]))) return rc;
         tr_commit("t_commit", cm[3]);
         tr_commit("h1_commit", cm[4]);
         tr_commit("h2_commit", cm[5]);
@@ -361,25 +370,22 @@ struct Prover {
         if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[7], 14, 3, 7))) return rc;         // z2: 3 blinders
         if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
         if ((rc = commit_begin(S.poly[7], n + 3, 1))) return rc;
-        for (int k = 0; k < 2; ++k) if ((rc = commit_end(k, &cm[6 + k]))) return rc;
-        tr_commit("z1_commit", cm[6]);
-        tr_commit("z2_commit", cm[7]);
-
-        // ---- round 4 (prove.rs:258-313) ----
+        for (int k : {W_Z1, W_Z2}) if ((rc = to_coset(k))) return rc;
+        // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well
         ZKT_HIP(c, hipMemsetAsync(S.ev[7], 0, n * 32, c->stream));
         for (size_t i = 0; i < in.n_pi; ++i) {
             if (in.pi_pos[i] >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "public input position out of range");
             ZKT_HIP(c, hipMemcpyAsync((char*)S.ev[7] + in.pi_pos[i] * 32, in.pi_vals + 4 * i, 32, hipMemcpyHostToDevice, c->stream));
         }
         if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[8], 0, 0, 8))) return rc;          // pi
+        if ((rc = to_coset(W_PI))) return rc;
+        for (int k = 0; k < 2; ++k) if ((rc = commit_end(k, &cm[6 + k]))) return rc;
+        tr_commit("z1_commit", cm[6]);
+        tr_commit("z2_commit", cm[7]);
+
+        // ---- round 4 (prove.rs:258-313) ----
         const F alpha = tr_challenge("alpha");
         {
-            // quotient_poly.rs:52-96 -- nine coset transforms on the 4n domain
-            const int src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
-            for (int k = 0; k < W_COUNT; ++k) {
-                if (k == W_T && S.t_coset_valid) continue;  // unchanged table: its coset is still resident
-                if ((rc = ntt_run(c, log_n + 2, 0, 1, S.poly[src[k]], n + 8, S.wcos[k]))) return rc;
-            }
             S.t_coset_valid = S.t_cached;
             QuotientArgs q{};
             q.a = S.wcos[W_A]; q.b = S.wcos[W_B]; q.c = S.wcos[W_C]; q.pi = S.wcos[W_PI];
