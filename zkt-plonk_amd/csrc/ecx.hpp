@@ -82,10 +82,12 @@ ZKT_HD XyzzX<Q> xx_double(const XyzzX<Q>& p) {
 }
 
 // madd-2008-s; q canonical, not the point at infinity.  This is the body of the MSM accumulation loop:
-// its ten products are inlined (INL) there, everything else calls the shared product.
+// there (INL) its products are inlined, the two squarings use the squaring kernel and Y3 = R (Q - X3) - Y1 PPP
+// is one double product with a single reduction; everything else calls the shared product.
 template <class Q, bool INL = false>
 ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
     auto mul = [](const Fx<Q>& a, const Fx<Q>& b) { return INL ? fx_mul_inl<Q>(a, b) : fx_mul<Q>(a, b); };
+    auto sqr = [](const Fx<Q>& a) { return INL ? fx_sqr_inl<Q>(a) : fx_mul<Q>(a, a); };
     if (p.inf) {
         XyzzX<Q> r;
         r.x = q.x;
@@ -99,8 +101,8 @@ ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
     const Fx<Q> s2 = mul(q.y, p.zzz);
     const Fx<Q> pp_ = fx_sub<Q, 8>(u2, p.x);           // < 10p
     const Fx<Q> rr = fx_sub<Q, 4>(s2, p.y);            // < 6p
-    const Fx<Q> pp = mul(pp_, pp_);                    // 100 p^2
-    const Fx<Q> rr2 = mul(rr, rr);
+    const Fx<Q> pp = sqr(pp_);                         // 100 p^2
+    const Fx<Q> rr2 = sqr(rr);
     if (fx_is_zero_lt2p<Q>(pp)) {                      // same x: P == Q or P == -Q
         if (fx_is_zero_lt2p<Q>(rr2)) return xx_double_affine<Q>(q);
         return xx_identity<Q>();
@@ -109,7 +111,12 @@ ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
     const Fx<Q> qq = mul(p.x, pp);
     XyzzX<Q> r;
     r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(rr2, ppp), fx_dbl<Q>(qq));                   // < 8p
-    r.y = fx_sub<Q, 2>(mul(rr, fx_sub<Q, 8>(qq, r.x)), mul(p.y, ppp));           // 6p * 10p ; < 4p
+    if (INL) {
+        // 6p * 10p + 4p * 2p < R' p ; < 2p
+        r.y = fx_mul2_inl<Q>(rr, fx_sub<Q, 8>(qq, r.x), fx_sub<Q, 4>(fx_zero<Q>(), p.y), ppp);
+    } else {
+        r.y = fx_sub<Q, 2>(mul(rr, fx_sub<Q, 8>(qq, r.x)), mul(p.y, ppp));       // 6p * 10p ; < 4p
+    }
     r.zz = mul(p.zz, pp);
     r.zzz = mul(p.zzz, ppp);
     r.inf = false;
