@@ -71,6 +71,27 @@ def test_synthetic_circuits_match_oracle(cv, gates, table_size, ctxs):
     assert P.verify(cv, tau, vk, want, P.new_seeded_transcript(cv, vk), pis)
 
 
+@pytest.mark.parametrize("n_public", [0, 1, 2, 15, 16, 17, 40])
+def test_public_input_counts(n_public, ctxs):
+    """Up to 16 public inputs the quotient kernel evaluates PI(X) from rotations of the l1 coset; beyond that
+    the polynomial goes through iNTT + coset NTT as in the reference (prove.rs:258-262).  Both must agree with
+    the oracle byte for byte, including the empty and the boundary cases."""
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    cs = P.synthetic_circuit(cv, 200, 16, seed=900 + n_public, n_public=n_public)
+    assert cs.check_satisfied()
+    assert len(cs.pi) <= n_public
+    n = cs.circuit_bound()
+    tau = 0x5151 + n_public
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(cv.fr.p, 4000 + n_public, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders)
+    got = _gpu_prove(z, ctxs[cv.name], cv, cs, pk, vk, srs_arr, blinders)
+    assert got == want.serialize(cv)
+
+
 def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
     """Second and third proof on the same loaded circuit take the cached-table path (same table), then a
     different table invalidates the cache; every proof must still equal the oracle's bytes."""

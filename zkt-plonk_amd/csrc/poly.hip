@@ -278,6 +278,8 @@ struct QuotientDev {
     FxArg gamma, epsilon, eopd;                                                    // A
     FxArg zh_inv[4];                                                               // H
     uint64_t n4;
+    const uint32_t* pi_tab;
+    uint32_t n_pi_direct;
 };
 template <class P>
 ZKT_D Fx<P> arg_fx(const FxArg& w) {
@@ -302,9 +304,30 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
     acc = fx_add<P>(acc, fx_mul<P>(a, LD(q.q_l, i)));
     acc = fx_add<P>(acc, fx_mul<P>(b, LD(q.q_r, i)));
     acc = fx_add<P>(acc, fx_mul<P>(c, LD(q.q_o, i)));
-    acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), LD(q.pi, i)));                 // < 10p
+    const X l1 = LD(q.l1, i);
+    if (q.pi_tab) {   // PI on the coset from rotations of l1 (poly.hpp); two terms per reduction, < 16p in all
+        X pi = fx_zero<P>();
+#pragma unroll 1
+        for (uint32_t e = 0; e < q.n_pi_direct; e += 2) {
+            X v[2], l[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t* ent = q.pi_tab + (size_t)(e + h) * 10;
+                const bool live = e + h < q.n_pi_direct;
+                const uint64_t rot = live ? ent[0] : 0;
+                const uint64_t at = (i >= rot) ? i - rot : i + q.n4 - rot;
+                l[h] = LD(q.l1, at);
+#pragma unroll
+                for (int w = 0; w < 9; ++w) v[h].l[w] = live ? ent[1 + w] : 0u;
+            }
+            pi = fx_add<P>(pi, fx_mul2_inl<P>(v[0], l[0], v[1], l[1]));
+        }
+        acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), pi));                      // < 25p
+    } else {
+        acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), LD(q.pi, i)));             // < 10p
+    }
     // keys/permutation.rs:97-137
-    const X z1 = LD(q.z1, i), z1n = LD(q.z1, j), l1 = LD(q.l1, i);
+    const X z1 = LD(q.z1, i), z1n = LD(q.z1, j);
     const X ag = fx_add<P>(a, gamma), bg = fx_add<P>(b, gamma), cg = fx_add<P>(c, gamma);   // < 2p
     const X one = fx_const_to_ark<P>();                                          // 1 in A form
     {
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
         p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma2, i), beta), bg));
         p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma3, i), beta), cg));
         const X p3 = fx_mul<P>(fx_mul<P>(fx_sub<P, 1>(z1, one), l1), arg_fx<P>(q.alpha2));
-        acc = fx_add<P>(acc, fx_add<P>(fx_sub<P, 2>(p1, p2), p3));               // < 16p
+        acc = fx_add<P>(acc, fx_add<P>(fx_sub<P, 2>(p1, p2), p3));               // < 31p
     }
     {   // keys/lookup.rs:81-122
         const X eps = arg_fx<P>(q.epsilon), eopd = arg_fx<P>(q.eopd);
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
         k2 = fx_mul<P>(k2, fx_add<P>(fx_add<P>(eopd, h2), fx_mul<P>(h1n, delta)));
         const X k3 = fx_mul<P>(fx_mul<P>(fx_sub<P, 1>(z2, one), l1), arg_fx<P>(q.alpha4));
         const X k4 = fx_mul<P>(fx_mul<P>(t, LD(q.q_table, i)), arg_fx<P>(q.alpha5));
-        acc = fx_add<P>(acc, fx_add<P>(fx_add<P>(fx_sub<P, 2>(k1, k2), k3), k4));   // < 24p
+        acc = fx_add<P>(acc, fx_add<P>(fx_add<P>(fx_sub<P, 2>(k1, k2), k3), k4));   // < 39p, times zh_inv < p: fits R' p
     }
 #undef LD
     // quotient_poly.rs:220-224: times zh_coset[i]^-1; x^n - 1 takes 4 values on the 4n coset
@@ -612,6 +635,10 @@ template <class P> static int quotient_t(zkt_ctx* c, const QuotientArgs& a) {
     q.eopd = ark_arg<P>(fe_mul<P>(eps, opd));
     for (int k = 0; k < 4; ++k) q.zh_inv[k] = hat_arg<P>(get(a.zh_inv[k]));
     q.n4 = a.n4;
+    q.pi_tab = a.pi_tab;
+    q.n_pi_direct = a.n_pi_direct;
+    if (a.pi_tab && a.n_pi_direct > (uint32_t)QUOTIENT_PI_DIRECT_MAX)
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "too many direct public inputs");
     hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(a.n4)), dim3(256), 0, c->stream, q);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;

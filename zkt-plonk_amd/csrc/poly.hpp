@@ -28,7 +28,13 @@ struct QuotientArgs {           // all vectors hold 4n coset evaluations
     uint32_t alpha[8], beta[8], gamma[8], delta[8], epsilon[8];
     uint32_t zh_inv[4][8];      // 1 / (x^n - 1) on the coset: depends on i mod 4 only
     uint64_t n4;
+    // Few public inputs: pi is not transformed at all.  PI(X) = sum_i v_i L_{pos_i}(X) and L_j(x) = L_0(x w^-j), so on
+    // the 4n coset PI[k] = sum_i v_i * l1[(k - 4 pos_i) mod 4n].  pi_tab (device): n_pi_direct entries of 10 words,
+    // {4 pos_i, nine 29-bit limbs of v_i (arkworks Montgomery form)}; `pi` is ignored when pi_tab is set.
+    const uint32_t* pi_tab;
+    uint32_t n_pi_direct;
 };
+constexpr int QUOTIENT_PI_DIRECT_MAX = 16;
 
 struct ZTermsArgs {
     const void *a, *b, *c, *s1, *s2, *s3, *roots;  // z1

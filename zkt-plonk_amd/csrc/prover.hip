@@ -47,6 +47,8 @@ struct CircuitState {
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
+    void* pinned_pi = nullptr;      // host staging of pi_tab
+    uint32_t* pi_tab = nullptr;     // device: QUOTIENT_PI_DIRECT_MAX entries of {rotation, 9 limbs}
     // The table polynomial depends on the lookup table only: while consecutive proofs pass the same table its
     // evaluations, coefficients, 4n-coset and commitment are reused (one MSM and two transforms less).
     std::vector<uint64_t> cached_table;
@@ -371,14 +373,27 @@ struct Prover {
         if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
         if ((rc = commit_begin(S.poly[7], n + 3, 1))) return rc;
         for (int k : {W_Z1, W_Z2}) if ((rc = to_coset(k))) return rc;
-        // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well
-        ZKT_HIP(c, hipMemsetAsync(S.ev[7], 0, n * 32, c->stream));
-        for (size_t i = 0; i < in.n_pi; ++i) {
+        // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well.  With a handful of
+        // public inputs it is never built: the quotient kernel evaluates it from rotations of l1 (poly.hpp).
+        for (size_t i = 0; i < in.n_pi; ++i)
             if (in.pi_pos[i] >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "public input position out of range");
-            ZKT_HIP(c, hipMemcpyAsync((char*)S.ev[7] + in.pi_pos[i] * 32, in.pi_vals + 4 * i, 32, hipMemcpyHostToDevice, c->stream));
+        const bool pi_direct = in.n_pi <= (size_t)QUOTIENT_PI_DIRECT_MAX;
+        if (pi_direct) {
+            uint32_t* tab = (uint32_t*)S.pinned_pi;
+            for (size_t i = 0; i < in.n_pi; ++i) {
+                tab[10 * i] = (uint32_t)(4 * in.pi_pos[i]);
+                const Fx<R> v = fx_unpack<R>(H::from_words(in.pi_vals + 4 * i));
+                for (int w = 0; w < 9; ++w) tab[10 * i + 1 + w] = v.l[w];
+            }
+            if (in.n_pi)
+                ZKT_HIP(c, hipMemcpyAsync(S.pi_tab, tab, in.n_pi * 40, hipMemcpyHostToDevice, c->stream));
+        } else {
+            ZKT_HIP(c, hipMemsetAsync(S.ev[7], 0, n * 32, c->stream));
+            for (size_t i = 0; i < in.n_pi; ++i)
+                ZKT_HIP(c, hipMemcpyAsync((char*)S.ev[7] + in.pi_pos[i] * 32, in.pi_vals + 4 * i, 32, hipMemcpyHostToDevice, c->stream));
+            if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[8], 0, 0, 8))) return rc;      // pi
+            if ((rc = to_coset(W_PI))) return rc;
         }
-        if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[8], 0, 0, 8))) return rc;          // pi
-        if ((rc = to_coset(W_PI))) return rc;
         for (int k = 0; k < 2; ++k) if ((rc = commit_end(k, &cm[6 + k]))) return rc;
         tr_commit("z1_commit", cm[6]);
         tr_commit("z2_commit", cm[7]);
@@ -398,6 +413,8 @@ struct Prover {
             put(q.alpha, alpha); put(q.beta, beta); put(q.gamma, gamma); put(q.delta, delta); put(q.epsilon, epsilon);
             memcpy(q.zh_inv, S.zh_inv, sizeof(q.zh_inv));
             q.n4 = 4 * n;
+            q.pi_tab = pi_direct ? S.pi_tab : nullptr;
+            q.n_pi_direct = pi_direct ? (uint32_t)in.n_pi : 0;
             if ((rc = quotient_pointwise(c, q))) return rc;
             if ((rc = ntt_run(c, log_n + 2, 1, 1, S.qev, 4 * n, S.qev))) return rc;         // quotient_poly.rs:226
             if ((rc = quotient_split_blind(c, S.qev, n, (const char*)S.small + 17 * 32, S.poly[9], S.poly[10], S.poly[11], S.status)))
@@ -571,8 +588,9 @@ static void circuit_release(zkt_ctx* c) {
     fr(S.scan_tmp);
     for (void* p : S.poly) fr(p);
     for (void* p : S.wcos) fr(p);
-    fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys);
+    fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab);
     if (S.pinned) (void)hipHostFree(S.pinned);
+    if (S.pinned_pi) (void)hipHostFree(S.pinned_pi);
     c->circuit.reset();
 }
 
@@ -614,6 +632,8 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     if ((rc = dev_alloc(c, (void**)&S.lk_u32, 3 * S.lk_cap * 4 + 16))) return rc;
     if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
+    ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
+    if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
 
     // extend_prover_key (keys/mod.rs:78-146) on the device
     const int pk_of_cs[10] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, PK_QLOOKUP, PK_QTABLE, PK_S1, PK_S2, PK_S3};
