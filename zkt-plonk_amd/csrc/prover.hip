@@ -347,29 +347,31 @@ struct Prover {
         za.num = S.sc[0]; za.den = S.sc[1]; za.n = n;
         put(za.beta, beta); put(za.gamma, gamma); put(za.delta, delta); put(za.epsilon, epsilon);
         F* pin = (F*)S.pinned;
-        // z1 into ev[7] (pi slot is filled later), z2 into sc[3] after use
+        // Both grand products are prefix products of num/den ratios; the division is one inversion of the total
+        // denominator on the host.  The two products are independent, so both pairs of scans run before the single
+        // host round trip (the second pair borrows the still unused z1 coset buffer).
+        void* pn2 = S.wcos[W_Z1];
+        void* sd2 = (char*)S.wcos[W_Z1] + n * 32;
         if ((rc = z1_terms(c, za))) return rc;
         if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;   // PN
         if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;    // SD
+        if ((rc = z2_terms(c, za))) return rc;
+        if ((rc = scan_mul(c, S.sc[0], pn2, n, false, S.scan_tmp))) return rc;
+        if ((rc = scan_mul(c, S.sc[1], sd2, n, true, S.scan_tmp))) return rc;
         ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipMemcpyAsync(pin + 1, sd2, 32, hipMemcpyDeviceToHost, c->stream));
         ZKT_HIP(c, hipStreamSynchronize(c->stream));
         if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the permutation grand product");
+        if (fe_is_zero<R>(pin[1])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the lookup grand product");
         {
-            F inv = fe_inv<R>(pin[0]);
-            if ((rc = z_combine(c, S.sc[2], S.sc[3], inv.v, S.ev[7], n))) return rc;
+            const F d1 = pin[0], d2 = pin[1];
+            const F inv12 = fe_inv<R>(fe_mul<R>(d1, d2));
+            const F inv1 = fe_mul<R>(inv12, d2), inv2 = fe_mul<R>(inv12, d1);
+            if ((rc = z_combine(c, S.sc[2], S.sc[3], inv1.v, S.ev[7], n))) return rc;
+            if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[6], 11, 3, 6))) return rc;     // z1: 3 blinders
+            if ((rc = z_combine(c, pn2, sd2, inv2.v, S.ev[7], n))) return rc;
+            if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[7], 14, 3, 7))) return rc;     // z2: 3 blinders
         }
-        if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[6], 11, 3, 6))) return rc;         // z1: 3 blinders
-        if ((rc = z2_terms(c, za))) return rc;
-        if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;
-        if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;
-        ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
-        ZKT_HIP(c, hipStreamSynchronize(c->stream));
-        if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the lookup grand product");
-        {
-            F inv = fe_inv<R>(pin[0]);
-            if ((rc = z_combine(c, S.sc[2], S.sc[3], inv.v, S.ev[7], n))) return rc;
-        }
-        if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[7], 14, 3, 7))) return rc;         // z2: 3 blinders
         if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
         if ((rc = commit_begin(S.poly[7], n + 3, 1))) return rc;
         for (int k : {W_Z1, W_Z2}) if ((rc = to_coset(k))) return rc;
@@ -419,7 +421,7 @@ struct Prover {
             if ((rc = ntt_run(c, log_n + 2, 1, 1, S.qev, 4 * n, S.qev))) return rc;         // quotient_poly.rs:226
             if ((rc = quotient_split_blind(c, S.qev, n, (const char*)S.small + 17 * 32, S.poly[9], S.poly[10], S.poly[11], S.status)))
                 return rc;
-            if ((rc = check_status())) return rc;
+            // an unsatisfied circuit shows up as status bits here; they are read with the evaluations of round 5
         }
         for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[9 + k], n + 3, k))) return rc;
         for (int k = 0; k < 3; ++k) if ((rc = commit_end(k, &cm[8 + k]))) return rc;
@@ -452,7 +454,7 @@ struct Prover {
         void* d_results = (char*)S.small + 32 * 32;
         if ((rc = poly_eval_many(c, ea, d_partials, d_results))) return rc;
         ZKT_HIP(c, hipMemcpyAsync(pin, d_results, 12 * 32, hipMemcpyDeviceToHost, c->stream));
-        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if ((rc = check_status())) return rc;   // synchronises the stream
         F ev[12];
         for (int k = 0; k < 12; ++k) ev[k] = pin[k];
         const F &e_a = ev[0], &e_b = ev[1], &e_c = ev[2], &e_s1 = ev[3], &e_s2 = ev[4], &e_z1n = ev[5], &e_ql = ev[6],
