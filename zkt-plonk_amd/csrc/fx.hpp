@@ -261,6 +261,22 @@ ZKT_HD Fx<P> fx_sub(const Fx<P>& a, const Fx<P>& b) {
     return r;
 }
 
+// a + K p - b with no carry propagation, for values that go straight into a product.  K p is re-expressed with
+// 2^29 borrowed into every limb from the one above, so each limb difference is non-negative whenever b's limbs are
+// normalised and b <= (K - 1) p (that keeps the top limb non-negative too).  Result limbs < 2^29 + 2^30: legal as
+// ONE operand of fx_mul / fx_mul_inl when the other is normalised (column sums stay below 2^64).
+template <class P, int K>
+ZKT_HD Fx<P> fx_sub_lazy(const Fx<P>& a, const Fx<P>& b) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const uint32_t fat = FxP<P>::kmod(K, i) + (i < L - 1 ? (1u << 29) : 0u) - (i > 0 ? 1u : 0u);
+        r.l[i] = a.l[i] + (fat - b.l[i]);
+    }
+    return r;
+}
+
 template <class P>
 ZKT_HD Fx<P> fx_dbl(const Fx<P>& a) { return fx_add<P>(a, a); }
 

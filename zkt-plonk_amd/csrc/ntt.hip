@@ -29,15 +29,45 @@ ZKT_D void tile_put(uint4* lo, uint4* hi, uint32_t* top, int idx, const Fx<P>& x
 
 ZKT_D uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
+// inner twiddles of a pass in LDS: R/2 entries.  Up to R = 128 they are kept unpacked (limbs, the tile's three-plane
+// layout); from R = 256 on the extra 4 bytes per entry would cost a resident workgroup per CU (4 x 40 KiB is exactly
+// the LDS), so they stay packed and are unpacked at every use.
+template <class P, bool UNPACKED>
+struct WTile {
+    const uint4* lo;
+    const uint4* hi;
+    const uint32_t* top;
+    ZKT_D Fx<P> get(int e) const {
+        if constexpr (UNPACKED) {
+            return tile_get<P>(lo, hi, top, e);
+        } else {
+            Fe<P> w;
+            const uint4 a = lo[e], b = hi[e];
+            w.v[0] = a.x; w.v[1] = a.y; w.v[2] = a.z; w.v[3] = a.w;
+            w.v[4] = b.x; w.v[5] = b.y; w.v[6] = b.z; w.v[7] = b.w;
+            return fx_unpack<P>(w);
+        }
+    }
+    ZKT_D static void put(uint4* lo, uint4* hi, uint32_t* top, int e, const Fe<P>& w) {
+        if constexpr (UNPACKED) {
+            tile_put<P>(lo, hi, top, e, fx_unpack<P>(w));
+        } else {
+            lo[e] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
+            hi[e] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
+        }
+    }
+};
+
 // One radix-2^G DIF step on 2^G elements held in registers (inputs < 2p, limbs normalised).
 //   level L: block size m = R >> L; element i sits at row blk*m + i*sub + off, sub = m >> G.
 //   sub-level l pairs (i, i + h), h = 2^(G-1-l); twiddle W_R^(((i & (h-1))*sub + off) << (L + l)).
-// Lazy bounds: at sub-level l the inputs are < 2^(l+1) p; sums double, differences get K = 2^(l+1)
+// Lazy bounds: at sub-level l the inputs are < 2^(l+1) p; sums double, differences get K = 2^(l+1) + 1
 // multiples of p added and are brought back below 2p by the twiddle product (twiddles are canonical,
-// R'-Montgomery form, so the product needs no more than a * p < R' p).  In the LAST step of a pass
-// (sub == 1, off == 0) the twiddle index depends on i only: W^0 products are skipped at compile time.
-template <class P, int G, bool LASTSTEP>
-ZKT_D void dif_group(Fx<P>* x, const Fe<P>* w_inner, int off, int sub, int L) {
+// R'-Montgomery form, so the product needs no more than a * p < R' p).  A difference that feeds a product
+// skips the carry pass altogether (fx_sub_lazy).  In the LAST step of a pass (sub == 1, off == 0) the
+// twiddle index depends on i only: W^0 products are skipped at compile time.
+template <class P, int G, bool LASTSTEP, class W>
+ZKT_D void dif_group(Fx<P>* x, const W& w, int off, int sub, int L) {
 #pragma unroll
     for (int l = 0; l < G; ++l) {
         const int h = 1 << (G - 1 - l);
@@ -46,23 +76,25 @@ ZKT_D void dif_group(Fx<P>* x, const Fe<P>* w_inner, int off, int sub, int L) {
             if ((i & h) == 0) {
                 const Fx<P> u = x[i], v = x[i + h];
                 x[i] = fx_add<P>(u, v);
-                Fx<P> d;
-                if (l == 0) d = fx_sub<P, 2>(u, v);
-                else if (l == 1) d = fx_sub<P, 4>(u, v);
-                else d = fx_sub<P, 8>(u, v);
-                if (LASTSTEP && (i & (h - 1)) == 0) {
-                    x[i + h] = d;  // twiddle is W^0 = 1
+                if (LASTSTEP && (i & (h - 1)) == 0) {   // twiddle is W^0 = 1
+                    if (l == 0) x[i + h] = fx_sub<P, 2>(u, v);
+                    else if (l == 1) x[i + h] = fx_sub<P, 4>(u, v);
+                    else x[i + h] = fx_sub<P, 8>(u, v);
                 } else {
+                    Fx<P> d;
+                    if (l == 0) d = fx_sub_lazy<P, 3>(u, v);
+                    else if (l == 1) d = fx_sub_lazy<P, 5>(u, v);
+                    else d = fx_sub_lazy<P, 9>(u, v);
                     const int e = ((i & (h - 1)) * sub + off) << (L + l);
-                    x[i + h] = fx_mul<P>(d, fx_unpack<P>(fe_load<P>(w_inner + e)));
+                    x[i + h] = fx_mul<P>(w.get(e), d);
                 }
             }
         }
     }
 }
 
-template <class P, int LOG_R, int G, int L>
-ZKT_D void dif_step(uint4* lo, uint4* hi, uint32_t* top, const Fe<P>* w_inner, int tid) {
+template <class P, int LOG_R, int G, int L, class W>
+ZKT_D void dif_step(uint4* lo, uint4* hi, uint32_t* top, const W& w_inner, int tid) {
     constexpr int R = 1 << LOG_R;
     constexpr int T = TILE >> LOG_R;
     constexpr int m = R >> L;
@@ -90,8 +122,8 @@ ZKT_D void dif_step(uint4* lo, uint4* hi, uint32_t* top, const Fe<P>* w_inner, i
     }
 }
 
-template <class P, int LOG_R>
-ZKT_D void dif_all(uint4* lo, uint4* hi, uint32_t* top, const Fe<P>* w, int tid) {
+template <class P, int LOG_R, class W>
+ZKT_D void dif_all(uint4* lo, uint4* hi, uint32_t* top, const W& w, int tid) {
     if constexpr (LOG_R == 5) {
         dif_step<P, 5, 3, 0>(lo, hi, top, w, tid); __syncthreads();
         dif_step<P, 5, 2, 3>(lo, hi, top, w, tid);
@@ -125,7 +157,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     __shared__ uint4 lds_lo[TILE];
     __shared__ uint4 lds_hi[TILE];
     __shared__ uint32_t lds_top[TILE];
-    __shared__ Fe<P> lds_w[R / 2];
+    constexpr bool W_UNPACKED = LOG_R <= 7;
+    typedef WTile<P, W_UNPACKED> WT;
+    __shared__ uint4 lds_w_lo[R / 2];
+    __shared__ uint4 lds_w_hi[R / 2];
+    __shared__ uint32_t lds_w_top[W_UNPACKED ? R / 2 : 1];
 
     const int tid = threadIdx.x;
     const Fe<P>* in = reinterpret_cast<const Fe<P>*>(a.in);
@@ -135,7 +171,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     const Fe<P>* tw = reinterpret_cast<const Fe<P>*>(a.tw);
     const Fe<P>* out_row = reinterpret_cast<const Fe<P>*>(a.out_row);
 
-    for (int i = tid; i < R / 2; i += NTT_THREADS) lds_w[i] = fe_load<P>(w_inner + i);
+    for (int i = tid; i < R / 2; i += NTT_THREADS) WT::put(lds_w_lo, lds_w_hi, lds_w_top, i, fe_load<P>(w_inner + i));
+    const WT lds_w{lds_w_lo, lds_w_hi, lds_w_top};
 
     const uint64_t tile = blockIdx.x;
     uint64_t in_base, out_base, tw_base;
