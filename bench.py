@@ -239,7 +239,11 @@ def main():
     msm_calls, msm_ms = prof["msm_main"]            # digits + sort + accumulate + bucket fold (main stream)
     tail_calls, tail_ms = prof["msm_tail"]          # bucket reduction (side stream, overlaps the next MSM)
     avg_msm_s = ((msm_ms + tail_ms) / max(msm_calls, 1)) * 1e-3
-    modmul_ceiling = N_SIMD * 64 * CLOCK_HZ / (171 * MAD_CYCLES)    # 171 v_mad_u64_u32 per 9x29-bit-limb Montgomery product
+    # One mixed addition (ecx.hpp xx_add_mixed, inlined) = 6 products + 2 squarings + 1 double product over
+    # L 29-bit limbs: 6 * 2L^2 + 2 * (L(L+1)/2 + L^2) + 3L^2 v_mad_u64_u32 (1467 for L = 9; the ISA has 1468).
+    Lq = -(-32 * 2 * L // 29)                                      # 9 (BN254 Fq), 14 (BLS12-381 Fq)
+    mads_per_add = 6 * 2 * Lq * Lq + 2 * (Lq * (Lq + 1) // 2 + Lq * Lq) + 3 * Lq * Lq
+    mad_ceiling = N_SIMD * 64 * CLOCK_HZ / MAD_CYCLES               # v_mad_u64_u32 issue ceiling, lanes/s
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
@@ -249,9 +253,10 @@ def main():
     int_alu = {
         "msm_g1_adds_per_s_reference_formula": round(ref_adds / avg_msm_s, 1) if avg_msm_s > 0 else None,
         "msm_mixed_adds_per_s_accumulate": round(mixed_adds / avg_acc_s, 1) if avg_acc_s > 0 else None,
-        "accumulate_modmul_per_s": round(10 * mixed_adds / avg_acc_s, 1) if avg_acc_s > 0 else None,
-        "modmul_ceiling_per_s": round(modmul_ceiling, 1),
-        "frac_of_mad_issue_ceiling": round(10 * mixed_adds / avg_acc_s / modmul_ceiling, 4) if avg_acc_s > 0 else None,
+        "mads_per_mixed_add": mads_per_add,
+        "accumulate_mad_per_s": round(mads_per_add * mixed_adds / avg_acc_s, 1) if avg_acc_s > 0 else None,
+        "mad_issue_ceiling_per_s": round(mad_ceiling, 1),
+        "frac_of_mad_issue_ceiling": round(mads_per_add * mixed_adds / avg_acc_s / mad_ceiling, 4) if avg_acc_s > 0 else None,
         "msm_avg_ms": round(avg_msm_s * 1e3, 4), "msm_launches": msm_calls,
         "msm_tail_avg_ms": round(tail_ms / max(tail_calls, 1), 4),
     }
