@@ -190,7 +190,9 @@ int zkt_debug_params(zkt_ctx* ctx, int which, uint32_t* out, size_t out_words);
 /* Runs a field routine on the HOST (the same __host__ __device__ code the kernels execute) so that
  * the arithmetic can be pinned against big integers without a GPU.  which: 0 = Fr, 1 = Fq; a, b, out:
  * packed Montgomery words (8 or 12 x u32).  op 0: product; 1: 32-bit-limb reference product;
- * 2: arkworks form -> 29-bit limbs -> arkworks form; 3: 3*(a^2 - b^2) through the lazy add/sub/mul path. */
+ * 2: arkworks form -> 29-bit limbs -> arkworks form; 3: 3*(a^2 - b^2) through the lazy add/sub/mul path;
+ * 4: a^-1 (host binary GCD); 5: a^-1 (the kernels' Fermat ladder); 6: a^2 + b^2 through the double product and
+ * the squaring kernel; 7: (a - b) * b through the carry-free difference. */
 int zkt_host_field_op(int curve_id, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
 /* Elementwise Fr product on the device (out[i] = a[i]*b[i], Montgomery); test hook for the field
  * kernels. Host pointers. */

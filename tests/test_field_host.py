@@ -37,3 +37,26 @@ def test_host_field_ops_match_big_integers(curve, which, f):
         # op 3: Montgomery-form inputs a~ = xR, b~ = yR  ->  (3 (x^2 - y^2)) R
         x, y = a * Rinv % p, b * Rinv % p
         assert _op(L, curve, which, 3, a, b, nw) == 3 * (x * x - y * y) * R % p
+        # op 6: a^2 + b^2 via the double product (one reduction) cross-checked with two squarings
+        assert _op(L, curve, which, 6, a, b, nw) == (x * x + y * y) * R % p
+        # op 7: (a - b) * b with the carry-free difference feeding the product
+        assert _op(L, curve, which, 7, a, b, nw) == (x - y) * y * R % p
+
+
+@pytest.mark.parametrize("curve,which,f", FIELDS, ids=lambda x: getattr(x, "name", str(x)))
+def test_host_inversions(curve, which, f):
+    """hostinv.hpp (binary extended Euclid, used between GPU phases) and the kernels' Fermat ladder against pow()."""
+    L = z.lib()
+    L.zkt_host_field_op.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_uint32)] * 3
+    p, nw = f.p, f.limbs64 * 2
+    R = 1 << (32 * nw)
+    rnd = random.Random(77 + curve * 2 + which)
+    vals = [1, 2, 3, p - 1, p - 2, R % p, (R * R) % p, p // 2, 1 << (f.bits - 1)] + [rnd.randrange(1, p) for _ in range(60)]
+    for a in vals:
+        x = a * pow(R, -1, p) % p                  # a is the Montgomery form of x
+        want = pow(x, -1, p) * R % p
+        assert _op(L, curve, which, 4, a, 0, nw) == want
+    for a in vals[:12]:
+        x = a * pow(R, -1, p) % p
+        assert _op(L, curve, which, 5, a, 0, nw) == pow(x, -1, p) * R % p
+    assert _op(L, curve, which, 4, 0, 0, nw) == 0

@@ -1,5 +1,6 @@
 // C-ABI entry points: context, memory plumbing, Domain seam (see include/zkt_plonk.h).
 #include "ctx.hpp"
+#include "hostinv.hpp"
 
 #include <cstring>
 
@@ -253,6 +254,9 @@ int zkt_debug_params(zkt_ctx* c, int which, uint32_t* out, size_t out_words) {
 // CPU test-suite pin the 29-bit-limb arithmetic against big integers without a GPU.
 //   op 0: packed Montgomery product (fe_mul)          op 1: 32-bit-limb CIOS reference (fe_mul_sat)
 //   op 2: ark -> R'-limbs -> ark round trip           op 3: lazy chain  (a + b) * (a + 8p - b) reduced
+//   op 4: a^-1 by the host's binary GCD (hostinv.hpp)  op 5: a^-1 by the kernels' Fermat ladder
+//   op 6: double product a*a + b*b with one reduction (fx_mul2_inl) and the squaring kernel, lazily summed
+//   op 7: (a + 3p - b) * b through the carry-free difference (fx_sub_lazy)
 template <class P>
 static void host_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     Fe<P> x, y, r;
@@ -264,6 +268,18 @@ static void host_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t
         r = fe_mul_sat<P>(x, y);
     } else if (op == 2) {
         r = fx_to_ark<P>(fx_from_ark<P>(x));
+    } else if (op == 4) {
+        r = fe_inv_host<P>(x);
+    } else if (op == 5) {
+        r = fe_inv<P>(x);
+    } else if (op == 6) {
+        const Fx<P> xa = fx_from_ark<P>(x), ya = fx_from_ark<P>(y);
+        const Fx<P> two = fx_mul2_inl<P>(xa, xa, ya, ya);                        // a^2 + b^2
+        const Fx<P> sq = fx_add<P>(fx_sqr_inl<P>(xa), fx_sqr_inl<P>(ya));       // the same, two reductions
+        r = fx_to_ark<P>(fx_sub<P, 4>(fx_add<P>(two, two), sq));               // 2 (a^2+b^2) - (a^2+b^2)
+    } else if (op == 7) {
+        const Fx<P> xa = fx_from_ark<P>(x), ya = fx_cond_sub_p<P>(fx_from_ark<P>(y));
+        r = fx_to_ark<P>(fx_mul<P>(ya, fx_sub_lazy<P, 3>(xa, ya)));             // (a - b) b
     } else {
         Fx<P> xa = fx_from_ark<P>(x), ya = fx_from_ark<P>(y);
         Fx<P> s = fx_add<P>(xa, ya);              // < 4p

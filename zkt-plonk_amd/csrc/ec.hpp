@@ -9,6 +9,7 @@
 #pragma once
 #include "fp.hpp"
 #include "fx.hpp"
+#include "hostinv.hpp"
 
 namespace zkt {
 
@@ -161,6 +162,22 @@ ZKT_HD Affine<Q> xyzz_to_affine(const Xyzz<Q>& p) {
         return r;
     }
     Fe<Q> inv = fe_inv<Q>(fe_mul<Q>(p.zz, p.zzz));
+    r.x = fe_mul<Q>(p.x, fe_mul<Q>(inv, p.zzz));  // X / ZZ
+    r.y = fe_mul<Q>(p.y, fe_mul<Q>(inv, p.zz));   // Y / ZZZ
+    return r;
+}
+
+// host-side normalisation (the prover needs the affine commitment for the transcript): same arithmetic with the
+// binary-GCD inversion of hostinv.hpp instead of the Fermat ladder the kernels use
+template <class Q>
+inline Affine<Q> xyzz_to_affine_host(const Xyzz<Q>& p) {
+    Affine<Q> r;
+    if (xyzz_is_identity<Q>(p)) {
+        r.x = fe_zero<Q>();
+        r.y = fe_zero<Q>();
+        return r;
+    }
+    Fe<Q> inv = fe_inv_host<Q>(fe_mul<Q>(p.zz, p.zzz));
     r.x = fe_mul<Q>(p.x, fe_mul<Q>(inv, p.zzz));  // X / ZZ
     r.y = fe_mul<Q>(p.y, fe_mul<Q>(inv, p.zz));   // Y / ZZZ
     return r;

@@ -909,7 +909,7 @@ static int msm_collect(zkt_ctx* c, int slot, Affine<typename C::Fq>* out) {
     st.pending[slot] = false;
     Xyzz<Q> r;
     memcpy(&r, st.host_result[slot], sizeof(r));
-    *out = xyzz_to_affine<Q>(r);
+    *out = xyzz_to_affine_host<Q>(r);
     return ZKT_OK;
 }
 

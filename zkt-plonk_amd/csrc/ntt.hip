@@ -1,5 +1,6 @@
 // NTT kernels + plan construction (see ntt.hpp for the decomposition).
 #include "ctx.hpp"
+#include "hostinv.hpp"
 
 namespace zkt {
 
@@ -395,16 +396,16 @@ static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>&
     split_log_n(log_n, &pl.npass, pl.log_r);
     const uint64_t N = (uint64_t)1 << log_n;
     Fe<P> w = root_of_unity<P>(log_n);
-    if (inverse) w = fe_inv<P>(w);
+    if (inverse) w = fe_inv_host<P>(w);
     Fe<P> g = fe_from_u32<P>(P::GENERATOR);
-    Fe<P> ginv = fe_inv<P>(g);
+    Fe<P> ginv = fe_inv_host<P>(g);
     Fe<P> one = fe_one<P>();
     Fe<P> ninv = one;
     if (inverse) {
         Fe<P> nn = fe_zero<P>();
         nn.v[0] = (uint32_t)(N & 0xffffffffu);
         nn.v[1] = (uint32_t)(N >> 32);
-        ninv = fe_inv<P>(fe_to_mont<P>(nn));
+        ninv = fe_inv_host<P>(fe_to_mont<P>(nn));
     }
     int rc;
     if (pl.npass == 0) {

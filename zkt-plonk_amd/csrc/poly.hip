@@ -484,6 +484,58 @@ __global__ __launch_bounds__(256) void k_lookup_count(const Fe<P>* f, size_t n, 
     }
 }
 
+// multiset.rs:126-143 on the device: every key contributes count/2 copies to both halves and, when its count is
+// odd, one more copy alternately to the even half and the odd half.  The alternation is a parity prefix, so the
+// start offsets of both halves are three exclusive scans.  One workgroup of 1024; status |= 8 when a half does not
+// end at n.
+__global__ __launch_bounds__(1024) void k_lookup_starts(const uint32_t* counts, uint32_t nk, uint32_t n,
+                                                        uint32_t* s_even, uint32_t* s_odd, uint32_t* status) {
+    __shared__ uint32_t wsum[3][16];
+    uint32_t carry[3] = {0, 0, 0};   // odd keys so far, even-half length, odd-half length
+    for (uint32_t base = 0; base < nk; base += 1024) {
+        const uint32_t k = base + threadIdx.x;
+        const uint32_t cnt = (k < nk) ? counts[k] : 0u;
+        uint32_t v[3] = {cnt & 1u, 0u, 0u};
+        uint32_t ex[3], tot[3];
+#pragma unroll 1
+        for (int q = 0; q < 3; ++q) {
+            if (q == 1) {   // the parity prefix is known now
+                const uint32_t odd_before = carry[0] + ex[0];
+                const uint32_t to_even = (cnt & 1u) && ((odd_before & 1u) == 0);
+                v[1] = (cnt >> 1) + (to_even ? 1u : 0u);
+                v[2] = (cnt >> 1) + (((cnt & 1u) && !to_even) ? 1u : 0u);
+            }
+            uint32_t incl = v[q];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((int)(threadIdx.x & 63) >= d) incl += o;
+            }
+            if ((threadIdx.x & 63) == 63) wsum[q][threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+            for (uint32_t w = 0; w < 16; ++w) {
+                const uint32_t x = wsum[q][w];
+                if (w < (threadIdx.x >> 6)) before += x;
+                all += x;
+            }
+            ex[q] = before + incl - v[q];
+            tot[q] = all;
+        }
+        if (k < nk) {
+            s_even[k] = carry[1] + ex[1];
+            s_odd[k] = carry[2] + ex[2];
+        }
+        __syncthreads();   // wsum is rewritten by the next chunk
+        for (int q = 0; q < 3; ++q) carry[q] += tot[q];
+    }
+    if (threadIdx.x == 0) {
+        s_even[nk] = carry[1];
+        s_odd[nk] = carry[2];
+        if (carry[1] != n || carry[2] != n) atomicOr(status, 8u);
+    }
+}
+
 // out[p] = key k with starts[k] <= p < starts[k+1]
 template <class P>
 __global__ void k_lookup_expand(const Fe<P>* keys, const uint32_t* starts, uint32_t nkeys, Fe<P>* out, size_t n) {
@@ -716,6 +768,13 @@ int lookup_count(zkt_ctx* c, const void* f, size_t n, const void* d_sorted_keys,
 }
 template <class P> static int lookup_expand_t(zkt_ctx* c, const void* keys, const uint32_t* starts, uint32_t nkeys, void* out, size_t n) {
     hipLaunchKernelGGL(k_lookup_expand<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Fe<P>*)keys, starts, nkeys, (Fe<P>*)out, n);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+int lookup_starts(zkt_ctx* c, const uint32_t* d_counts, uint32_t nkeys, size_t n, uint32_t* d_even, uint32_t* d_odd,
+                  uint32_t* d_status) {
+    hipLaunchKernelGGL(k_lookup_starts, dim3(1), dim3(1024), 0, c->stream, d_counts, nkeys, (uint32_t)n, d_even, d_odd,
+                       d_status);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }

@@ -72,6 +72,10 @@ int gen_powers(zkt_ctx* c, void* out, size_t n, const uint32_t base[8], const ui
 // Plookup sorted halves h1/h2 (lookup/multiset.rs:103-146)
 int lookup_count(zkt_ctx* c, const void* f, size_t n, const void* d_sorted_keys, const uint32_t* d_perm, uint32_t nkeys,
                  uint32_t* d_counts, uint32_t* d_status);
+// start offsets of both halves of combine_split (multiset.rs:126-143) from the per-key counts; nkeys + 1 entries each.
+// d_status |= 8 when a half does not come out at n elements.
+int lookup_starts(zkt_ctx* c, const uint32_t* d_counts, uint32_t nkeys, size_t n, uint32_t* d_even, uint32_t* d_odd,
+                  uint32_t* d_status);
 int lookup_expand(zkt_ctx* c, const void* d_keys_insertion, const uint32_t* d_starts, uint32_t nkeys, void* out, size_t n);
 
 }  // namespace zkt

@@ -3,6 +3,7 @@
 // polynomial stays in HBM between rounds; only commitments (affine points), the 12 evaluations and
 // two scalars (the grand-product denominators) cross PCIe, for the host-side Fiat-Shamir transcript.
 #include "ctx.hpp"
+#include "hostinv.hpp"
 #include "ec.hpp"
 #include "poly.hpp"
 #include "transcript.hpp"
@@ -43,7 +44,7 @@ struct CircuitState {
     void* qev = nullptr;    // 4n
     void* small = nullptr;  // blinders (19), eval partials, eval results
     uint32_t* status = nullptr;  // [0] error bits, [1] len scratch ... [4..7] quotient lens, [8..] poly lens
-    uint32_t* lk_u32 = nullptr;  // lookup: perm, counts, starts
+    uint32_t* lk_u32 = nullptr;  // lookup: perm, counts, starts of the even half, starts of the odd half
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
@@ -176,17 +177,26 @@ struct Prover {
         ZKT_HIP(c, hipMemcpyAsync(&st, S.status, 4, hipMemcpyDeviceToHost, c->stream));
         ZKT_HIP(c, hipStreamSynchronize(c->stream));
         if (st & 4u) return set_err(c, ZKT_ERR_NOT_IN_TABLE, "ElementNotIndexedInTable: a looked-up value is not in the table");
+        if (st & 8u) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "combine_split: h1/h2 length differs from n");
         if (st & 2u) return set_err(c, ZKT_ERR_QUOTIENT_TOO_SHORT, "quotient degree exceeds 3n+5: the circuit is not satisfied");
         if (st & 1u) return set_err(c, ZKT_ERR_QUOTIENT_TOO_SHORT, "quotient polynomial too short to split (prove.rs:287-300)");
         return ZKT_OK;
     }
 
     // lookup/multiset.rs:103-146 on the device; table = distinct values in insertion order
+    std::vector<F> lk_host_keys, lk_host_sorted;
+    std::vector<uint32_t> lk_host_counts, lk_host_order;
     int combine_split(const uint64_t* table, size_t table_len) {
         const size_t n = S.n;
-        std::vector<F> keys(table_len);
+        // host staging lives in the prover object (alive until the proof's final synchronisation): the copies
+        // below are asynchronous and nothing here waits
+        std::vector<F>& keys = lk_host_keys;
+        std::vector<F>& sorted = lk_host_sorted;
+        std::vector<uint32_t>& counts = lk_host_counts;
+        std::vector<uint32_t>& order = lk_host_order;
+        keys.resize(table_len);
         for (size_t i = 0; i < table_len; ++i) keys[i] = H::from_words(table + 4 * i);
-        std::vector<uint32_t> counts(table_len, 1u);
+        counts.assign(table_len, 1u);
         // t is padded with zeros to n (lookup/table.rs:52-61): they join the zero key or create it
         size_t zero_idx = table_len;
         for (size_t i = 0; i < table_len; ++i)
@@ -203,7 +213,7 @@ struct Prover {
         }
         const uint32_t nk = (uint32_t)keys.size();
         if (nk + 2 > S.lk_cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "lookup table larger than the circuit bound");
-        std::vector<uint32_t> order(nk);
+        order.resize(nk);
         for (uint32_t i = 0; i < nk; ++i) order[i] = i;
         auto less = [&](uint32_t a, uint32_t b) {
             for (int i = R::N - 1; i >= 0; --i) {
@@ -212,50 +222,25 @@ struct Prover {
             return false;
         };
         std::sort(order.begin(), order.end(), less);
-        std::vector<F> sorted(nk);
+        sorted.resize(nk);
         for (uint32_t i = 0; i < nk; ++i) sorted[i] = keys[order[i]];
         F* d_keys = (F*)S.lk_keys;
         F* d_sorted = d_keys + S.lk_cap;
         uint32_t* d_perm = S.lk_u32;
         uint32_t* d_counts = S.lk_u32 + S.lk_cap;
-        uint32_t* d_starts = S.lk_u32 + 2 * S.lk_cap;
+        uint32_t* d_even = S.lk_u32 + 2 * S.lk_cap;
+        uint32_t* d_odd = S.lk_u32 + 3 * S.lk_cap;
         ZKT_HIP(c, hipMemcpyAsync(d_keys, keys.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
         ZKT_HIP(c, hipMemcpyAsync(d_sorted, sorted.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
         ZKT_HIP(c, hipMemcpyAsync(d_perm, order.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
         ZKT_HIP(c, hipMemcpyAsync(d_counts, counts.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
         int rc;
+        // a looked-up value outside the table sets status bit 4 (ElementNotIndexedInTable); like the other status
+        // bits it is read at the next host round trip
         if ((rc = lookup_count(c, S.ev[4], n, d_sorted, d_perm, nk, d_counts, S.status))) return rc;
-        ZKT_HIP(c, hipMemcpyAsync(counts.data(), d_counts, nk * 4, hipMemcpyDeviceToHost, c->stream));
-        if ((rc = check_status())) return rc;
-        // multiset.rs:126-143: halves and the alternating odd element
-        std::vector<uint32_t> s_even(nk + 1), s_odd(nk + 1);
-        uint32_t pe = 0, po = 0;
-        bool parity = false;
-        for (uint32_t k = 0; k < nk; ++k) {
-            s_even[k] = pe;
-            s_odd[k] = po;
-            uint32_t half = counts[k] / 2;
-            pe += half;
-            po += half;
-            if (counts[k] & 1u) {
-                if (parity) {
-                    po += 1;
-                    parity = false;
-                } else {
-                    pe += 1;
-                    parity = true;
-                }
-            }
-        }
-        s_even[nk] = pe;
-        s_odd[nk] = po;
-        if (pe != n || po != n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "combine_split: h1/h2 length differs from n");
-        ZKT_HIP(c, hipMemcpyAsync(d_starts, s_even.data(), (nk + 1) * 4, hipMemcpyHostToDevice, c->stream));
-        if ((rc = lookup_expand(c, d_keys, d_starts, nk, S.ev[5], n))) return rc;
-        ZKT_HIP(c, hipStreamSynchronize(c->stream));  // s_even is reused by the driver's staging copy
-        ZKT_HIP(c, hipMemcpyAsync(d_starts, s_odd.data(), (nk + 1) * 4, hipMemcpyHostToDevice, c->stream));
-        if ((rc = lookup_expand(c, d_keys, d_starts, nk, S.ev[6], n))) return rc;
-        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if ((rc = lookup_starts(c, d_counts, nk, n, d_even, d_odd, S.status))) return rc;   // multiset.rs:126-143
+        if ((rc = lookup_expand(c, d_keys, d_even, nk, S.ev[5], n))) return rc;
+        if ((rc = lookup_expand(c, d_keys, d_odd, nk, S.ev[6], n))) return rc;
         return ZKT_OK;
     }
 
@@ -360,12 +345,12 @@ struct Prover {
         if ((rc = scan_mul(c, S.sc[1], sd2, n, true, S.scan_tmp))) return rc;
         ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
         ZKT_HIP(c, hipMemcpyAsync(pin + 1, sd2, 32, hipMemcpyDeviceToHost, c->stream));
-        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if ((rc = check_status())) return rc;   // synchronises; reports a lookup outside the table (round 2)
         if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the permutation grand product");
         if (fe_is_zero<R>(pin[1])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the lookup grand product");
         {
             const F d1 = pin[0], d2 = pin[1];
-            const F inv12 = fe_inv<R>(fe_mul<R>(d1, d2));
+            const F inv12 = fe_inv_host<R>(fe_mul<R>(d1, d2));
             const F inv1 = fe_mul<R>(inv12, d2), inv2 = fe_mul<R>(inv12, d1);
             if ((rc = z_combine(c, S.sc[2], S.sc[3], inv1.v, S.ev[7], n))) return rc;
             if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[6], 11, 3, 6))) return rc;     // z1: 3 blinders
@@ -469,7 +454,7 @@ struct Prover {
         nn = fe_to_mont<R>(nn);
         const F l1den = fe_mul<R>(nn, fe_sub<R>(xi, one));
         if (fe_is_zero<R>(l1den)) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "xi = 1");
-        const F l1 = fe_mul<R>(zh, fe_inv<R>(l1den));
+        const F l1 = fe_mul<R>(zh, fe_inv_host<R>(l1den));
         const F a2 = fe_sqr<R>(alpha), a3 = fe_mul<R>(a2, alpha), a4 = fe_mul<R>(a3, alpha), a5 = fe_mul<R>(a4, alpha);
         const F k1 = fe_from_u32<R>(7), k2 = fe_from_u32<R>(13);
         const F bxi = fe_mul<R>(beta, xi);
@@ -538,7 +523,7 @@ struct Prover {
             }
             void* comb = S.sc[0];  // n + 8 fits: sc buffers hold n + 8 elements
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
-            F zi = fe_inv<R>(xi);
+            F zi = fe_inv_host<R>(xi);
             if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
             if ((rc = commit_begin(S.sc[3], cap - 1, 0))) return rc;  // the scalars are consumed by the first kernel
         }
@@ -552,7 +537,7 @@ struct Prover {
             }
             void* comb = S.sc[0];
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
-            F zi = fe_inv<R>(shifted);
+            F zi = fe_inv_host<R>(shifted);
             if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
             if ((rc = commit_begin(S.sc[3], cap - 1, 1))) return rc;
             if ((rc = commit_end(0, &aw))) return rc;
@@ -631,7 +616,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
     S.lk_cap = n + 2;
-    if ((rc = dev_alloc(c, (void**)&S.lk_u32, 3 * S.lk_cap * 4 + 16))) return rc;
+    if ((rc = dev_alloc(c, (void**)&S.lk_u32, 4 * S.lk_cap * 4 + 16))) return rc;
     if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
@@ -655,7 +640,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
         F nn = fe_zero<R>();
         nn.v[0] = (uint32_t)(n & 0xffffffffu);
         nn.v[1] = (uint32_t)((uint64_t)n >> 32);
-        F ninv = fe_inv<R>(fe_to_mont<R>(nn));
+        F ninv = fe_inv_host<R>(fe_to_mont<R>(nn));
         if ((rc = gen_powers(c, S.ev[0], n, one.v, ninv.v))) return rc;
         if ((rc = ntt_run(c, log_n + 2, 0, 1, S.ev[0], n, S.coset[CS_L1]))) return rc;
     }
@@ -670,7 +655,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
         for (int j = 0; j < 4; ++j) {
             F zh = fe_sub<R>(cur, one);
             if (fe_is_zero<R>(zh)) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "vanishing polynomial is zero on the coset");
-            F inv = fe_inv<R>(zh);
+            F inv = fe_inv_host<R>(zh);
             memcpy(S.zh_inv[j], inv.v, 32);
             cur = fe_mul<R>(cur, w4);
         }
@@ -785,9 +770,11 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
     if (c->curve == ZKT_CURVE_BN254) {
         Prover<Bn254Curve> p(c, *c->circuit, tr);
         rc = p.run(*in, proof);
+        if (rc) (void)hipStreamSynchronize(c->stream);   // an early return may leave staged copies in flight
     } else {
         Prover<Bls381Curve> p(c, *c->circuit, tr);
         rc = p.run(*in, proof);
+        if (rc) (void)hipStreamSynchronize(c->stream);
     }
     if (rc) return rc;
     if (len) *len = proof.size();
