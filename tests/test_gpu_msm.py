@@ -115,6 +115,37 @@ def test_msm_random_matches_oracle(cv, log_n, ctxs):
     assert not inf and np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("shape", ["all_equal", "small", "three_values", "sparse", "top_bits"])
+def test_msm_skewed_digit_distributions(shape, ctxs):
+    """The bucket grouping (two-level counting sort) and the chunked accumulation must not depend on the digits
+    being uniform: a single crowded bucket per window (many level-2 tiles in one bin, the heavy-bucket fold),
+    empty high windows, a handful of distinct digits, mostly-zero scalars."""
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    n = (1 << 16) + 321
+    ctx.srs_generate(0xD15EA5E, n)
+    srs = ctx.srs_download(0, n)
+    rng = np.random.default_rng(sum(map(ord, shape)))
+    p = cv.fr.p
+    if shape == "all_equal":
+        vals = [0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF12345678 % p] * n
+    elif shape == "small":
+        vals = [int(x) for x in rng.integers(0, 1 << 16, size=n)]
+    elif shape == "three_values":
+        pool = [p - 1, (1 << 253) % p, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF]
+        vals = [pool[int(i)] for i in rng.integers(0, 3, size=n)]
+    elif shape == "sparse":
+        vals = [0] * n
+        for i in rng.integers(0, n, size=50):
+            vals[int(i)] = int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % p
+    else:
+        vals = [(int(x) << 238) % p for x in rng.integers(1, 1 << 15, size=n)]
+    sc = K.fr_to_mont(cv, vals)
+    out, inf = ctx.msm(sc)
+    want, winf = K.msm_mont(cv, srs, sc)
+    assert inf == winf and np.array_equal(out, want)
+
+
 def test_msm_full_size_2_20(ctxs):
     """BASELINE config 3: 2^20 scalars/points, bit-exact commitment (BN254), plus linearity."""
     cv = F.BN254
