@@ -8,6 +8,8 @@ import zkt_plonk_amd as z
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+shared = len(sys.argv) > 3 and sys.argv[3] == "shared"   # all contexts enqueue on ONE stream: kernels never overlap
+shared_stream = None
 log_n = 20
 fld = B.FIELDS["bn254"]
 n = 1 << log_n
@@ -17,7 +19,11 @@ L = fld["fq_limbs"]
 workers = []
 for w in range(F):
     ctx = z.Context("bn254", 0)
-    s = torch.cuda.Stream(dev)
+    if shared:
+        shared_stream = shared_stream or torch.cuda.Stream(dev)
+        s = shared_stream
+    else:
+        s = torch.cuda.Stream(dev)
     ctx.set_stream(s.cuda_stream)
     ctx.srs_generate(0x5EED5EED1234567890ABCDEF % fld["r"], n + 8)
     pk = {name: ctx.ntt(log_n, B.fr_to_mont_gpu(ctx, fld, circ["sel"][name]), inverse=True) for name in z.PK_ORDER}
@@ -55,5 +61,5 @@ for x in th: x.join()
 torch.cuda.synchronize()
 el = time.perf_counter() - t
 total = (steps // F) * F
-print("inflight=%d: %d proofs in %.3f s -> %.2f proofs/s (%.2f ms/proof); proofs identical: %s" % (
+print(("shared-stream " if shared else "") + "inflight=%d: %d proofs in %.3f s -> %.2f proofs/s (%.2f ms/proof); proofs identical: %s" % (
     F, total, el, total / el, 1e3 * el / total, all(p == proofs[0] for p in proofs)), flush=True)

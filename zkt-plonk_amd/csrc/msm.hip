@@ -253,8 +253,9 @@ __global__ __launch_bounds__(1024) void k_msm_scan_tiles(uint32_t* counts, uint3
     }
     if (threadIdx.x == 0) aux[blockIdx.x] = all;
 }
-// aux[0 .. nt) -> exclusive, aux[nt] = grand total.  One workgroup.
-__global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t nt) {
+// aux[0 .. nt) -> exclusive, aux[nt] = grand total.  One workgroup.  Also resets the crowded-bucket counter of this
+// MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
+__global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t nt, uint32_t* heavy_count) {
     __shared__ uint32_t wsum[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nt; base += 1024) {
@@ -265,7 +266,10 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t n
         if (i < nt) aux[i] = carry + ex;
         carry += all;
     }
-    if (threadIdx.x == 0) aux[nt] = carry;
+    if (threadIdx.x == 0) {
+        aux[nt] = carry;
+        *heavy_count = 0;
+    }
 }
 ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, size_t total) {
     return (i < total) ? offs[i] + aux[i / MSM_SCAN_TILE] : aux[(total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE];
@@ -841,7 +845,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         hipLaunchKernelGGL(k_msm_bin_count<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream,
                            (const Fe<R>*)d_scalars, n, mont, st.win, S, st.nb1, st.bin_offs);
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
-        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_aux, ntiles);
+        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_aux, ntiles, st.heavy);
         ZKT_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 8 + (size_t)MSM_L1_CAP * 8,
                            c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S, st.count, base_off, st.nb1,
@@ -867,7 +871,6 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     }
     // the slot's tail buffers may still be read by the previous MSM that used this slot
     if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
-    ZKT_HIP(c, hipMemsetAsync(st.heavy, 0, 4, c->stream));
     hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
                        chunk, (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());

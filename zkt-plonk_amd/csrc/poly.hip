@@ -23,7 +23,11 @@ __global__ void k_mul_vec(const Fe<P>* a, const Fe<P>* b, Fe<P>* o, size_t n) {
 
 // number of coefficients after stripping trailing zeros (DensePolynomial::from_coefficients_vec)
 template <class P>
-__global__ void k_trim_len(const Fe<P>* p, size_t lo, size_t n, uint32_t* len, int skip_if_set) {
+__global__ void k_trim_len(const Fe<P>* p, size_t lo, size_t n, uint32_t* len, int skip_if_set, Fe<P>* zero_at,
+                           int zero_count) {
+    // the first launch also clears the few coefficients above the transform's output (they held the previous
+    // proof's blinders); nothing in this launch reads them
+    if (zero_at && blockIdx.x == 0 && (int)threadIdx.x < zero_count) fe_store<P>(zero_at + threadIdx.x, fe_zero<P>());
     // Scans [lo, n).  The polynomials are dense, so the answer is almost always in the last few hundred
     // coefficients: the caller first scans that tail with one small launch and this launch returns at once
     // when the tail already produced a result (same-address atomics serialise at ~13 ns each).
@@ -488,13 +492,19 @@ __global__ __launch_bounds__(256) void k_lookup_count(const Fe<P>* f, size_t n, 
 // odd, one more copy alternately to the even half and the odd half.  The alternation is a parity prefix, so the
 // start offsets of both halves are three exclusive scans.  One workgroup of 1024; status |= 8 when a half does not
 // end at n.
-__global__ __launch_bounds__(1024) void k_lookup_starts(const uint32_t* counts, uint32_t nk, uint32_t n,
+// counts[k] = base[k] (multiplicity in the padded table) + hits[k] (occurrences in f); hits is cleared on the way so
+// that the next proof finds it zero without a memset.
+__global__ __launch_bounds__(1024) void k_lookup_starts(const uint32_t* base_counts, uint32_t* hits, uint32_t nk, uint32_t n,
                                                         uint32_t* s_even, uint32_t* s_odd, uint32_t* status) {
     __shared__ uint32_t wsum[3][16];
     uint32_t carry[3] = {0, 0, 0};   // odd keys so far, even-half length, odd-half length
     for (uint32_t base = 0; base < nk; base += 1024) {
         const uint32_t k = base + threadIdx.x;
-        const uint32_t cnt = (k < nk) ? counts[k] : 0u;
+        uint32_t cnt = 0;
+        if (k < nk) {
+            cnt = base_counts[k] + hits[k];
+            hits[k] = 0;
+        }
         uint32_t v[3] = {cnt & 1u, 0u, 0u};
         uint32_t ex[3], tot[3];
 #pragma unroll 1
@@ -567,6 +577,20 @@ static Fe<P> host_fe(const uint32_t* w) {
     return r;
 }
 
+// out[0..n) = in[0..len) followed by zeros (prove.rs:39-55 pad_to)
+template <class P>
+__global__ void k_copy_pad(const Fe<P>* in, size_t len, Fe<P>* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store<P>(out + i, i < len ? fe_load<P>(in + i) : fe_zero<P>());
+}
+template <class P> static int copy_pad_t(zkt_ctx* c, const void* in, size_t len, void* out, size_t n) {
+    if (!n) return ZKT_OK;
+    hipLaunchKernelGGL(k_copy_pad<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Fe<P>*)in, len, (Fe<P>*)out, n);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+int poly_copy_pad(zkt_ctx* c, const void* d_in, size_t len, void* out, size_t n) { ZKT_DISPATCH(c, copy_pad_t, d_in, len, out, n); }
+
 template <class P> static int mul_vec_t(zkt_ctx* c, const void* a, const void* b, void* o, size_t n) {
     if (!n) return ZKT_OK;
     hipLaunchKernelGGL(k_mul_vec<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Fe<P>*)a, (const Fe<P>*)b, (Fe<P>*)o, n);
@@ -580,19 +604,27 @@ int poly_set_zero(zkt_ctx* c, void* p, size_t n_elems) {
     return ZKT_OK;
 }
 
-template <class P> static int trim_len_t(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len) {
-    ZKT_HIP(c, hipMemsetAsync(d_len, 0, 4, c->stream));
+// *d_len must be zero on entry (the prover clears all its length slots with the status words at proof start)
+template <class P> static int trim_len_t(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len, void* zero_at = nullptr,
+                                         int zero_count = 0) {
     if (!n) return ZKT_OK;
     const size_t tail = n > 1024 ? n - 1024 : 0;
-    hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(n - tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, tail, n, d_len, 0);
+    hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(n - tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, tail, n, d_len, 0,
+                       (Fe<P>*)zero_at, zero_count);
     ZKT_HIP(c, hipGetLastError());
     if (tail) {  // full scan, a no-op unless the top 1024 coefficients were all zero
-        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, (size_t)0, tail, d_len, 1);
+        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(tail)), dim3(256), 0, c->stream, (const Fe<P>*)p, (size_t)0, tail, d_len, 1,
+                           (Fe<P>*)nullptr, 0);
         ZKT_HIP(c, hipGetLastError());
     }
     return ZKT_OK;
 }
-int poly_trim_len(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len) { ZKT_DISPATCH(c, trim_len_t, p, n, d_len); }
+template <class P> static int trim_len_pub_t(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len, void* zero_at, int zero_count) {
+    return trim_len_t<P>(c, p, n, d_len, zero_at, zero_count);
+}
+int poly_trim_len(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len, void* zero_at, int zero_count) {
+    ZKT_DISPATCH(c, trim_len_pub_t, p, n, d_len, zero_at, zero_count);
+}
 
 template <class P> static int add_blinders_t(zkt_ctx* c, void* p, const uint32_t* d_len, const void* bl, int k) {
     hipLaunchKernelGGL(k_add_blinders<P>, dim3(1), dim3(64), 0, c->stream, (Fe<P>*)p, d_len, (const Fe<P>*)bl, k);
@@ -704,25 +736,34 @@ template <class P> static int to_hat_t(zkt_ctx* c, void* v, size_t n, int k32) {
 int to_hat_form(zkt_ctx* c, void* v, size_t n, int k32) { ZKT_DISPATCH(c, to_hat_t, v, n, k32); }
 int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a) { ZKT_DISPATCH(c, quotient_t, a); }
 
+// prove.rs:287-289: the three (n+2)-coefficient chunks of the quotient, each zero-padded to its buffer
+template <class P>
+__global__ void k_quot_split(const Fe<P>* q, size_t chunk, size_t cap, Fe<P>* lo, Fe<P>* mid, Fe<P>* hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const bool in = i < chunk;
+    const Fe<P> z = fe_zero<P>();
+    fe_store<P>(lo + i, in ? fe_load<P>(q + i) : z);
+    fe_store<P>(mid + i, in ? fe_load<P>(q + chunk + i) : z);
+    fe_store<P>(hi + i, in ? fe_load<P>(q + 2 * chunk + i) : z);
+}
+
 template <class P> static int quot_split_t(zkt_ctx* c, const void* q, size_t n, const void* b0b1, void* lo, void* mid, void* hi, uint32_t* d_status) {
-    // d_status[0] = error bits ; d_status[4..7] = lens (lo, mid, hi, q)
+    // d_status[0] = error bits ; d_status[4..7] = lens (lo, mid, hi, q), zero on entry
     const Fe<P>* Q = (const Fe<P>*)q;
     const size_t cap = n + 8, chunk = n + 2;
-    ZKT_HIP(c, hipMemsetAsync(lo, 0, cap * 32, c->stream));
-    ZKT_HIP(c, hipMemsetAsync(mid, 0, cap * 32, c->stream));
-    ZKT_HIP(c, hipMemsetAsync(hi, 0, cap * 32, c->stream));
-    ZKT_HIP(c, hipMemcpyAsync(lo, Q, chunk * 32, hipMemcpyDeviceToDevice, c->stream));
-    ZKT_HIP(c, hipMemcpyAsync(mid, Q + chunk, chunk * 32, hipMemcpyDeviceToDevice, c->stream));
-    ZKT_HIP(c, hipMemcpyAsync(hi, Q + 2 * chunk, chunk * 32, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_quot_split<P>, dim3(nblocks(cap)), dim3(256), 0, c->stream, Q, chunk, cap, (Fe<P>*)lo, (Fe<P>*)mid,
+                       (Fe<P>*)hi);
+    ZKT_HIP(c, hipGetLastError());
     uint32_t* lens = d_status + 4;
     int rc;
     if ((rc = trim_len_t<P>(c, lo, chunk, lens + 0))) return rc;
     if ((rc = trim_len_t<P>(c, mid, chunk, lens + 1))) return rc;
     if ((rc = trim_len_t<P>(c, hi, chunk, lens + 2))) return rc;
     {   // only "is anything non-zero at or above 3(n+2)?" matters for the quotient itself
-        ZKT_HIP(c, hipMemsetAsync(lens + 3, 0, 4, c->stream));
         const size_t lo = 3 * chunk, hi = 4 * n;
-        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(hi - lo)), dim3(256), 0, c->stream, (const Fe<P>*)q, lo, hi, lens + 3, 0);
+        hipLaunchKernelGGL(k_trim_len<P>, dim3(nblocks(hi - lo)), dim3(256), 0, c->stream, (const Fe<P>*)q, lo, hi, lens + 3, 0,
+                           (Fe<P>*)nullptr, 0);
         ZKT_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_quot_blind<P>, dim3(1), dim3(64), 0, c->stream, (Fe<P>*)lo, (Fe<P>*)mid, (Fe<P>*)hi, lens, (const Fe<P>*)b0b1, (uint32_t)n, d_status);
@@ -771,10 +812,10 @@ template <class P> static int lookup_expand_t(zkt_ctx* c, const void* keys, cons
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
-int lookup_starts(zkt_ctx* c, const uint32_t* d_counts, uint32_t nkeys, size_t n, uint32_t* d_even, uint32_t* d_odd,
-                  uint32_t* d_status) {
-    hipLaunchKernelGGL(k_lookup_starts, dim3(1), dim3(1024), 0, c->stream, d_counts, nkeys, (uint32_t)n, d_even, d_odd,
-                       d_status);
+int lookup_starts(zkt_ctx* c, const uint32_t* d_base_counts, uint32_t* d_hits, uint32_t nkeys, size_t n, uint32_t* d_even,
+                  uint32_t* d_odd, uint32_t* d_status) {
+    hipLaunchKernelGGL(k_lookup_starts, dim3(1), dim3(1024), 0, c->stream, d_base_counts, d_hits, nkeys, (uint32_t)n, d_even,
+                       d_odd, d_status);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }

@@ -47,7 +47,10 @@ struct ZTermsArgs {
 // elementwise
 int poly_mul_vec(zkt_ctx* c, const void* a, const void* b, void* out, size_t n);              // prove.rs:157-161
 int poly_set_zero(zkt_ctx* c, void* p, size_t n_elems);
-int poly_trim_len(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len);                       // from_coefficients_vec
+// from_coefficients_vec: *d_len (zero on entry) = number of coefficients after stripping trailing zeros of p[0..n);
+// optionally clears zero_count elements at zero_at in the same launch (the slack above a transform's output)
+int poly_trim_len(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len, void* zero_at = nullptr, int zero_count = 0);
+int poly_copy_pad(zkt_ctx* c, const void* d_in, size_t len, void* out, size_t n);   // prove.rs:39-55 pad_to
 int poly_add_blinders(zkt_ctx* c, void* p, const uint32_t* d_len, const void* d_blinders, int k, size_t cap);  // prove.rs:472-483
 int poly_lincomb(zkt_ctx* c, const LinCombArgs& a, void* out, size_t n);
 int poly_eval_many(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results);         // linearization_poly.rs:55-75
@@ -72,10 +75,10 @@ int gen_powers(zkt_ctx* c, void* out, size_t n, const uint32_t base[8], const ui
 // Plookup sorted halves h1/h2 (lookup/multiset.rs:103-146)
 int lookup_count(zkt_ctx* c, const void* f, size_t n, const void* d_sorted_keys, const uint32_t* d_perm, uint32_t nkeys,
                  uint32_t* d_counts, uint32_t* d_status);
-// start offsets of both halves of combine_split (multiset.rs:126-143) from the per-key counts; nkeys + 1 entries each.
-// d_status |= 8 when a half does not come out at n elements.
-int lookup_starts(zkt_ctx* c, const uint32_t* d_counts, uint32_t nkeys, size_t n, uint32_t* d_even, uint32_t* d_odd,
-                  uint32_t* d_status);
+// start offsets of both halves of combine_split (multiset.rs:126-143) from the per-key counts base + hits; nkeys + 1
+// entries each.  d_hits is cleared on the way.  d_status |= 8 when a half does not come out at n elements.
+int lookup_starts(zkt_ctx* c, const uint32_t* d_base_counts, uint32_t* d_hits, uint32_t nkeys, size_t n, uint32_t* d_even,
+                  uint32_t* d_odd, uint32_t* d_status);
 int lookup_expand(zkt_ctx* c, const void* d_keys_insertion, const uint32_t* d_starts, uint32_t nkeys, void* out, size_t n);
 
 }  // namespace zkt

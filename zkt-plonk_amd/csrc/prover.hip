@@ -44,7 +44,8 @@ struct CircuitState {
     void* qev = nullptr;    // 4n
     void* small = nullptr;  // blinders (19), eval partials, eval results
     uint32_t* status = nullptr;  // [0] error bits, [1] len scratch ... [4..7] quotient lens, [8..] poly lens
-    uint32_t* lk_u32 = nullptr;  // lookup: perm, counts, starts of the even half, starts of the odd half
+    uint32_t* lk_u32 = nullptr;  // lookup: perm, base counts, starts of the even half, of the odd half, hit counts
+    uint32_t lk_nkeys = 0;       // keys of the resident lookup tables (0 = none)
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
@@ -163,11 +164,12 @@ struct Prover {
         const size_t n = S.n;
         int rc;
         if ((rc = ntt_run(c, S.log_n, 1, 0, ev, n, poly))) return rc;
-        ZKT_HIP(c, hipMemsetAsync((char*)poly + n * 32, 0, 8 * 32, c->stream));
         if (k > 0) {
-            if ((rc = poly_trim_len(c, poly, n, S.status + 8 + len_slot))) return rc;
+            if ((rc = poly_trim_len(c, poly, n, S.status + 8 + len_slot, (char*)poly + n * 32, 8))) return rc;
             if ((rc = poly_add_blinders(c, poly, S.status + 8 + len_slot, (const char*)S.small + (size_t)blinder_off * 32, k, n + 8)))
                 return rc;
+        } else {
+            ZKT_HIP(c, hipMemsetAsync((char*)poly + n * 32, 0, 8 * 32, c->stream));
         }
         return ZKT_OK;
     }
@@ -186,59 +188,67 @@ struct Prover {
     // lookup/multiset.rs:103-146 on the device; table = distinct values in insertion order
     std::vector<F> lk_host_keys, lk_host_sorted;
     std::vector<uint32_t> lk_host_counts, lk_host_order;
-    int combine_split(const uint64_t* table, size_t table_len) {
+    // `fresh` = the lookup table differs from the previous proof's: its keys (insertion order and sorted), the
+    // sort permutation and the base multiplicities are rebuilt and uploaded; otherwise they are still resident.
+    int combine_split(const uint64_t* table, size_t table_len, bool fresh) {
         const size_t n = S.n;
-        // host staging lives in the prover object (alive until the proof's final synchronisation): the copies
-        // below are asynchronous and nothing here waits
-        std::vector<F>& keys = lk_host_keys;
-        std::vector<F>& sorted = lk_host_sorted;
-        std::vector<uint32_t>& counts = lk_host_counts;
-        std::vector<uint32_t>& order = lk_host_order;
-        keys.resize(table_len);
-        for (size_t i = 0; i < table_len; ++i) keys[i] = H::from_words(table + 4 * i);
-        counts.assign(table_len, 1u);
-        // t is padded with zeros to n (lookup/table.rs:52-61): they join the zero key or create it
-        size_t zero_idx = table_len;
-        for (size_t i = 0; i < table_len; ++i)
-            if (fe_is_zero<R>(keys[i])) {
-                zero_idx = i;
-                break;
-            }
-        if (n > table_len) {
-            if (zero_idx == table_len) {
-                keys.push_back(fe_zero<R>());
-                counts.push_back(0);
-            }
-            counts[zero_idx] += (uint32_t)(n - table_len);
-        }
-        const uint32_t nk = (uint32_t)keys.size();
-        if (nk + 2 > S.lk_cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "lookup table larger than the circuit bound");
-        order.resize(nk);
-        for (uint32_t i = 0; i < nk; ++i) order[i] = i;
-        auto less = [&](uint32_t a, uint32_t b) {
-            for (int i = R::N - 1; i >= 0; --i) {
-                if (keys[a].v[i] != keys[b].v[i]) return keys[a].v[i] < keys[b].v[i];
-            }
-            return false;
-        };
-        std::sort(order.begin(), order.end(), less);
-        sorted.resize(nk);
-        for (uint32_t i = 0; i < nk; ++i) sorted[i] = keys[order[i]];
         F* d_keys = (F*)S.lk_keys;
         F* d_sorted = d_keys + S.lk_cap;
         uint32_t* d_perm = S.lk_u32;
-        uint32_t* d_counts = S.lk_u32 + S.lk_cap;
+        uint32_t* d_base = S.lk_u32 + S.lk_cap;
         uint32_t* d_even = S.lk_u32 + 2 * S.lk_cap;
         uint32_t* d_odd = S.lk_u32 + 3 * S.lk_cap;
-        ZKT_HIP(c, hipMemcpyAsync(d_keys, keys.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
-        ZKT_HIP(c, hipMemcpyAsync(d_sorted, sorted.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
-        ZKT_HIP(c, hipMemcpyAsync(d_perm, order.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
-        ZKT_HIP(c, hipMemcpyAsync(d_counts, counts.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
+        uint32_t* d_hits = S.lk_u32 + 4 * S.lk_cap;   // zero between proofs (k_lookup_starts clears what it reads)
+        if (fresh || S.lk_nkeys == 0) {
+            // host staging lives in the prover object (alive until the proof's final synchronisation): the copies
+            // below are asynchronous and nothing here waits
+            std::vector<F>& keys = lk_host_keys;
+            std::vector<F>& sorted = lk_host_sorted;
+            std::vector<uint32_t>& counts = lk_host_counts;
+            std::vector<uint32_t>& order = lk_host_order;
+            keys.resize(table_len);
+            for (size_t i = 0; i < table_len; ++i) keys[i] = H::from_words(table + 4 * i);
+            counts.assign(table_len, 1u);
+            // t is padded with zeros to n (lookup/table.rs:52-61): they join the zero key or create it
+            size_t zero_idx = table_len;
+            for (size_t i = 0; i < table_len; ++i)
+                if (fe_is_zero<R>(keys[i])) {
+                    zero_idx = i;
+                    break;
+                }
+            if (n > table_len) {
+                if (zero_idx == table_len) {
+                    keys.push_back(fe_zero<R>());
+                    counts.push_back(0);
+                }
+                counts[zero_idx] += (uint32_t)(n - table_len);
+            }
+            const uint32_t nk = (uint32_t)keys.size();
+            if (nk + 2 > S.lk_cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "lookup table larger than the circuit bound");
+            order.resize(nk);
+            for (uint32_t i = 0; i < nk; ++i) order[i] = i;
+            auto less = [&](uint32_t a, uint32_t b) {
+                for (int i = R::N - 1; i >= 0; --i) {
+                    if (keys[a].v[i] != keys[b].v[i]) return keys[a].v[i] < keys[b].v[i];
+                }
+                return false;
+            };
+            std::sort(order.begin(), order.end(), less);
+            sorted.resize(nk);
+            for (uint32_t i = 0; i < nk; ++i) sorted[i] = keys[order[i]];
+            ZKT_HIP(c, hipMemcpyAsync(d_keys, keys.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
+            ZKT_HIP(c, hipMemcpyAsync(d_sorted, sorted.data(), nk * 32, hipMemcpyHostToDevice, c->stream));
+            ZKT_HIP(c, hipMemcpyAsync(d_perm, order.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
+            ZKT_HIP(c, hipMemcpyAsync(d_base, counts.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
+            ZKT_HIP(c, hipMemsetAsync(d_hits, 0, (size_t)nk * 4, c->stream));   // a failed proof may have left counts behind
+            S.lk_nkeys = nk;
+        }
+        const uint32_t nk = S.lk_nkeys;
         int rc;
         // a looked-up value outside the table sets status bit 4 (ElementNotIndexedInTable); like the other status
         // bits it is read at the next host round trip
-        if ((rc = lookup_count(c, S.ev[4], n, d_sorted, d_perm, nk, d_counts, S.status))) return rc;
-        if ((rc = lookup_starts(c, d_counts, nk, n, d_even, d_odd, S.status))) return rc;   // multiset.rs:126-143
+        if ((rc = lookup_count(c, S.ev[4], n, d_sorted, d_perm, nk, d_hits, S.status))) return rc;
+        if ((rc = lookup_starts(c, d_base, d_hits, nk, n, d_even, d_odd, S.status))) return rc;   // multiset.rs:126-143
         if ((rc = lookup_expand(c, d_keys, d_even, nk, S.ev[5], n))) return rc;
         if ((rc = lookup_expand(c, d_keys, d_odd, nk, S.ev[6], n))) return rc;
         return ZKT_OK;
@@ -264,10 +274,13 @@ struct Prover {
         // ---- round 1 (prove.rs:116-140) ----
         const uint64_t* wires[3] = {in.a_evals, in.b_evals, in.c_evals};
         for (int k = 0; k < 3; ++k) {
-            ZKT_HIP(c, hipMemsetAsync(S.ev[k], 0, n * 32, c->stream));
-            if (in.n_rows)
-                ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32,
-                                          in.wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+            if (in.wires_on_device) {
+                if ((rc = poly_copy_pad(c, wires[k], in.n_rows, S.ev[k], n))) return rc;   // prove.rs:39-55 pad_to
+            } else {
+                ZKT_HIP(c, hipMemsetAsync(S.ev[k], 0, n * 32, c->stream));
+                if (in.n_rows)
+                    ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32, hipMemcpyHostToDevice, c->stream));
+            }
             if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
         }
         Affine<Q> cm[11];
@@ -291,7 +304,7 @@ struct Prover {
             if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;      // t: no blinders
         }
         if ((rc = poly_mul_vec(c, S.q_lookup_ev, S.ev[2], S.ev[4], n))) return rc;         // f = q_lookup . c
-        if ((rc = combine_split(in.table, in.table_len))) return rc;
+        if ((rc = combine_split(in.table, in.table_len, !same_table))) return rc;
         if ((rc = evals_to_blinded_poly(S.ev[5], S.poly[4], 6, 3, 4))) return rc;          // h1: 3 blinders
         if ((rc = evals_to_blinded_poly(S.ev[6], S.poly[5], 9, 2, 5))) return rc;          // h2: 2 blinders
         if (!same_table && (rc = commit_begin(S.poly[3], n, 3))) return rc;
@@ -616,7 +629,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
     S.lk_cap = n + 2;
-    if ((rc = dev_alloc(c, (void**)&S.lk_u32, 4 * S.lk_cap * 4 + 16))) return rc;
+    if ((rc = dev_alloc(c, (void**)&S.lk_u32, 5 * S.lk_cap * 4 + 16))) return rc;
     if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
