@@ -162,23 +162,22 @@ def main():
     ctx.srs_generate(0x5EED5EED1234567890ABCDEF % fld["r"], n + 8)
 
     circ = synthetic_circuit(fld, log_n)
-    pk = {}
-    for name in z.PK_ORDER:
-        evals = fr_to_mont_gpu(ctx, fld, circ["sel"][name])
-        pk[name] = ctx.ntt(log_n, evals, inverse=True)            # setup.rs:72-90: selector / sigma polynomials
-    rinv_q = pow(1 << (64 * fld["fq_limbs"]), -1, fld["q"])
-    vk = {}
+    # proof_system::setup on the device (setup.rs:42-166): selector / sigma / table-mask evaluations -> ProverKey,
+    # ExtendedProverKey and the ten VerifierKey commitments that seed the transcript
+    evals = {name: fr_to_mont_gpu(ctx, fld, circ["sel"][name]) for name in z.PK_ORDER}
+    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    del evals
     L = fld["fq_limbs"]
-    for name in z.PK_ORDER:                                        # setup.rs:104-121: the ten key commitments
-        xy, inf = ctx.msm(pk[name])
+    rinv_q = pow(1 << (64 * L), -1, fld["q"])
+    vk = {}
+    for name in z.PK_ORDER:
+        xy, inf = commits[name]
         if inf:
             vk[name] = None
         else:
             x = sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv_q % fld["q"]
             y = sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv_q % fld["q"]
             vk[name] = (x, y)
-    prover = z.GpuProver(ctx, log_n, pk)
-    del pk
     gates = circ["gates"]
     wires = [torch.from_numpy(fr_to_mont_gpu(ctx, fld, circ[k][:gates]).view(np.int64)).to(dev) for k in "abc"]
     table = fr_to_mont_gpu(ctx, fld, circ["table"])

@@ -153,6 +153,17 @@ typedef struct {
  * the device and stays resident in HBM; it never crosses PCIe. */
 int zkt_circuit_load(zkt_ctx* ctx, int log_n, const uint64_t* const* pk_polys, const size_t* pk_lens);
 
+/* proof_system::setup on the device (plonk-core/src/proof_system/setup.rs:42-166): the ten padded evaluation vectors
+ * of the SetupComposer in ProverKey order (q_m, q_l, q_r, q_o, q_c, sigma1, sigma2, sigma3, q_lookup, q_table;
+ * eval_lens[k] <= n values each, the rest zero - setup.rs:28-35 pad_to) become the ProverKey polynomials (iNTT), the
+ * ExtendedProverKey (as in zkt_circuit_load) and the ten VerifierKey commitments (PC::commit, setup.rs:104-121).
+ * out_commitments: 10 x (x, y) in arkworks Montgomery limbs (2 x 4 u64 on BN254, 2 x 6 on BLS12-381), (0, 0) and
+ * out_is_infinity[k] = 1 for the identity (an all-zero selector).  The circuit is left loaded: zkt_prove can follow.
+ * Needs zkt_srs_load with >= n powers.  The permutation bookkeeping that produces the sigma evaluations
+ * (permutation/mod.rs compute_all_sigma_evals) stays with the caller. */
+int zkt_circuit_setup(zkt_ctx* ctx, int log_n, const uint64_t* const* evals, const size_t* eval_lens, int evals_on_device,
+                      uint64_t* out_commitments, int* out_is_infinity);
+
 typedef struct {
     /* wire_evals() of the proving composer (prove.rs:49-55,116): n_rows <= n values each, zero padded */
     const uint64_t* a_evals;
@@ -171,7 +182,18 @@ typedef struct {
     const uint64_t* blinders;
     /* non-zero: a_evals / b_evals / c_evals are DEVICE pointers (witness already resident in HBM) */
     int wires_on_device;
+    /* Alternative to the three evaluation vectors, used when a_evals is NULL: the witness as the composer holds it
+     * (prove.rs:49-55 wire_evals runs on the device).  `variables`: n_vars assigned values (var_map, Montgomery
+     * form); w_l / w_r / w_o: n_rows variable indices per gate, ZKT_VARIABLE_ZERO = Variable::Zero (value 0,
+     * constraint_system/variable.rs:10-15).  An index >= n_vars -> ZKT_ERR_INVALID_ARGUMENT.  wires_on_device
+     * applies to these four arrays as well. */
+    const uint64_t* variables;
+    size_t n_vars;
+    const uint32_t* w_l;
+    const uint32_t* w_r;
+    const uint32_t* w_o;
 } zkt_prove_inputs;
+#define ZKT_VARIABLE_ZERO 0xFFFFFFFFu
 
 /* Runs the five prover rounds on the device and writes the CanonicalSerialize bytes of
  * Proof<F, D, KZG10<E>> (proof.rs:106-155): 802 bytes on BN254, 1010 on BLS12-381.  The transcript must

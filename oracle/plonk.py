@@ -294,8 +294,9 @@ def commit(be: Backend, srs: Sequence[Point], poly: Sequence[int]) -> Point:
     return be.msm(srs[:len(poly)], list(poly))
 
 
-def setup(be: Backend, srs: Sequence[Point], cs: ConstraintSystem, extend: bool = True):
-    """proof_system/setup.rs:42-166."""
+def setup_evals(be: Backend, cs: ConstraintSystem) -> Dict[str, List[int]]:
+    """The ten evaluation vectors setup.rs:62-90 transforms: padded selectors (setup.rs:28-35), sigma evaluations
+    (permutation/mod.rs:139-156) and the table mask (lookup/table.rs:42-48)."""
     cv = be.cv
     p = cv.fr.p
     n = cs.circuit_bound()
@@ -310,6 +311,16 @@ def setup(be: Backend, srs: Sequence[Point], cs: ConstraintSystem, extend: bool 
     q_table = [0] * cs.table_size + [1] * (n - cs.table_size)                          # table.rs:42-48
     evals = dict(sel)
     evals.update(sigma1=sig_evals[0], sigma2=sig_evals[1], sigma3=sig_evals[2], q_table=q_table)
+    return evals
+
+
+def setup(be: Backend, srs: Sequence[Point], cs: ConstraintSystem, extend: bool = True):
+    """proof_system/setup.rs:42-166."""
+    n = cs.circuit_bound()
+    roots = be.domain(n).elements()
+    evals = setup_evals(be, cs)
+    sel = evals
+    sig_evals = [evals["sigma1"], evals["sigma2"], evals["sigma3"]]
     polys = {k: trim(be.ifft(n, evals[k])) for k in PK_POLYS}
     commits = {k: commit(be, srs, polys[k]) for k in PK_POLYS}
     pi_roots = [roots[i] for i in sorted(cs.pi.keys())]

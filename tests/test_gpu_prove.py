@@ -92,6 +92,76 @@ def test_public_input_counts(n_public, ctxs):
     assert got == want.serialize(cv)
 
 
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_setup_on_the_device(cv, ctxs):
+    """zkt_circuit_setup = proof_system::setup (setup.rs:42-166): from the SetupComposer's evaluation vectors to the
+    VerifierKey commitments and a loaded prover; both against the oracle's setup + prove."""
+    import zkt_plonk_amd as z
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 700, 32, seed=4242)
+    n = cs.circuit_bound()
+    tau = 0x7E57
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    evals = P.setup_evals(be, cs)
+    ctx.srs_load(srs_arr)
+    prover, commits = z.GpuProver.setup(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, evals[k]) for k in z.PK_ORDER})
+    q = cv.fq.p
+    rinv = pow(1 << (64 * cv.fq.limbs64), -1, q)
+    L = cv.fq.limbs64
+    for name in z.PK_ORDER:
+        xy, inf = commits[name]
+        want = vk.commits[name]
+        if want is None:
+            assert inf
+            continue
+        x = sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % q
+        y = sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % q
+        assert not inf and (x, y) == want, name
+    blinders = field_elems(cv.fr.p, 31, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders)
+    a, b, c = cs.wire_evals(cs.n_gates)
+    tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * L)
+    z.seed_transcript(tr, n, vk.commits)
+    got = prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
+                       {i: K.fr_to_mont(cv, [v])[0] for i, v in cs.pi.items()}, K.fr_to_mont(cv, blinders), tr)
+    assert got == want.serialize(cv)
+
+
+def test_witness_gather_on_the_device(ctxs):
+    """prove.rs:49-55 wire_evals on the device: the composer's variable map + per-gate index vectors give the same
+    proof as the three evaluation vectors; an index outside the map is an error."""
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 500, 32, seed=55)
+    n = cs.circuit_bound()
+    tau = 0xABBA
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(cv.fr.p, 9, P.NUM_BLINDERS)
+    want = _gpu_prove(z, ctx, cv, cs, pk, vk, srs_arr, blinders)
+    assert want == P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    to_idx = lambda ws: np.array([0xFFFFFFFF if v == P.ZERO_VAR else v for v in ws], dtype=np.uint32)
+    pi_pos = sorted(cs.pi)
+    pi_vals = K.fr_to_mont(cv, [cs.pi[k] for k in pi_pos])
+
+    def run(w_l):
+        tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+        z.seed_transcript(tr, vk.n, vk.commits)
+        return ctx.prove_vars(K.fr_to_mont(cv, cs.values), w_l, to_idx(cs.w_r), to_idx(cs.w_o), K.fr_to_mont(cv, cs.table),
+                              pi_pos, pi_vals, K.fr_to_mont(cv, blinders), tr)
+
+    assert run(to_idx(cs.w_l)) == want
+    bad = to_idx(cs.w_l)
+    bad[3] = len(cs.values)          # one past the last variable
+    with pytest.raises(z.ZktError) as e:
+        run(bad)
+    assert e.value.code == 1
+
+
 def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
     """Second and third proof on the same loaded circuit take the cached-table path (same table), then a
     different table invalidates the cache; every proof must still equal the oracle's bytes."""

@@ -95,7 +95,10 @@ class ProveInputs(ctypes.Structure):
                 ("table", ctypes.POINTER(ctypes.c_uint64)), ("table_len", ctypes.c_size_t),
                 ("pi_pos", ctypes.POINTER(ctypes.c_size_t)), ("pi_vals", ctypes.POINTER(ctypes.c_uint64)),
                 ("n_pi", ctypes.c_size_t), ("blinders", ctypes.POINTER(ctypes.c_uint64)),
-                ("wires_on_device", ctypes.c_int)]
+                ("wires_on_device", ctypes.c_int),
+                ("variables", ctypes.POINTER(ctypes.c_uint64)), ("n_vars", ctypes.c_size_t),
+                ("w_l", ctypes.POINTER(ctypes.c_uint32)), ("w_r", ctypes.POINTER(ctypes.c_uint32)),
+                ("w_o", ctypes.POINTER(ctypes.c_uint32))]
 
 
 def _bind_prover(L):
@@ -116,6 +119,8 @@ def _bind_prover(L):
     L.zkt_transcript_append_message.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     L.zkt_transcript_challenge_bytes.argtypes = [vp, ctypes.c_char_p, u8p, ctypes.c_size_t]
     L.zkt_circuit_load.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64p_), ctypes.POINTER(ctypes.c_size_t)]
+    L.zkt_circuit_setup.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64p_), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int,
+                                    u64p_, ctypes.POINTER(ctypes.c_int)]
     L.zkt_prove.argtypes = [vp, ctypes.POINTER(ProveInputs), vp, u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
 
 
@@ -303,6 +308,19 @@ class Context:
         lens = (ctypes.c_size_t * 10)(*[a.shape[0] for a in arrs])
         self.check(self._L.zkt_circuit_load(self._h, log_n, ptrs, lens))
 
+    def circuit_setup(self, log_n: int, evals):
+        """proof_system::setup (setup.rs:42-166) on the device.  evals: the 10 evaluation vectors (len_k <= n, 4) in
+        ProverKey order, Montgomery limbs.  Leaves the circuit loaded; -> (commitments (10, 2*fq_limbs) Montgomery
+        limbs, is_infinity (10,) bool) = the VerifierKey commitments in the same order."""
+        arrs = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in evals]
+        assert len(arrs) == 10
+        ptrs = (ctypes.POINTER(ctypes.c_uint64) * 10)(*[u64p(a) if a.size else ctypes.POINTER(ctypes.c_uint64)() for a in arrs])
+        lens = (ctypes.c_size_t * 10)(*[a.shape[0] for a in arrs])
+        out = np.zeros((10, 2 * self.fq_limbs), dtype=np.uint64)
+        inf = (ctypes.c_int * 10)()
+        self.check(self._L.zkt_circuit_setup(self._h, log_n, ptrs, lens, 0, u64p(out), inf))
+        return out, np.array([bool(x) for x in inf])
+
     def prove_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
         """Same as prove() with the three wire vectors already resident in HBM (device pointers)."""
         table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
@@ -329,6 +347,27 @@ class Context:
         inp = ProveInputs(u64p(a) if a.size else null, u64p(b) if b.size else null, u64p(c) if c.size else null,
                           a.shape[0], u64p(table) if table.size else null, table.shape[0], pos,
                           u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 0)
+        out = (ctypes.c_uint8 * 2048)()
+        n = ctypes.c_size_t(0)
+        self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))
+        return bytes(out[:n.value])
+
+    def prove_vars(self, variables, w_l, w_r, w_o, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
+        """proof_system::prove from the composer's own witness layout: `variables` (n_vars, 4) Montgomery values and
+        three uint32 index vectors (0xFFFFFFFF = Variable::Zero); prove.rs:49-55 wire_evals runs on the device."""
+        variables = np.ascontiguousarray(variables, dtype=np.uint64).reshape(-1, 4)
+        idx = [np.ascontiguousarray(w, dtype=np.uint32).reshape(-1) for w in (w_l, w_r, w_o)]
+        assert idx[0].shape == idx[1].shape == idx[2].shape
+        table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+        pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
+        blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
+        pos = (ctypes.c_size_t * max(1, len(pi_pos)))(*pi_pos)
+        null = ctypes.POINTER(ctypes.c_uint64)()
+        u32p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        inp = ProveInputs(null, null, null, idx[0].shape[0], u64p(table) if table.size else null, table.shape[0], pos,
+                          u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 0,
+                          u64p(variables) if variables.size else null, variables.shape[0], u32p(idx[0]), u32p(idx[1]),
+                          u32p(idx[2]))
         out = (ctypes.c_uint8 * 2048)()
         n = ctypes.c_size_t(0)
         self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))

@@ -583,6 +583,35 @@ __global__ void k_copy_pad(const Fe<P>* in, size_t len, Fe<P>* out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) fe_store<P>(out + i, i < len ? fe_load<P>(in + i) : fe_zero<P>());
 }
+// prove.rs:49-55 wire_evals + pad_to: out[i] = values[idx[i]] for i < rows (0 for Variable::Zero), zero above
+template <class P>
+__global__ void k_gather_pad(const Fe<P>* values, uint32_t n_vars, const uint32_t* idx, size_t rows, Fe<P>* out, size_t n,
+                             uint32_t* status) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<P> v = fe_zero<P>();
+    if (i < rows) {
+        const uint32_t k = idx[i];
+        if (k != 0xFFFFFFFFu) {
+            if (k < n_vars) v = fe_load<P>(values + k);
+            else atomicOr(status, 16u);
+        }
+    }
+    fe_store<P>(out + i, v);
+}
+template <class P> static int gather_pad_t(zkt_ctx* c, const void* values, size_t n_vars, const uint32_t* idx, size_t rows,
+                                           void* out, size_t n, uint32_t* status) {
+    if (!n) return ZKT_OK;
+    hipLaunchKernelGGL(k_gather_pad<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Fe<P>*)values, (uint32_t)n_vars, idx,
+                       rows, (Fe<P>*)out, n, status);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+int poly_gather_pad(zkt_ctx* c, const void* d_values, size_t n_vars, const uint32_t* d_idx, size_t rows, void* out, size_t n,
+                    uint32_t* d_status) {
+    ZKT_DISPATCH(c, gather_pad_t, d_values, n_vars, d_idx, rows, out, n, d_status);
+}
+
 template <class P> static int copy_pad_t(zkt_ctx* c, const void* in, size_t len, void* out, size_t n) {
     if (!n) return ZKT_OK;
     hipLaunchKernelGGL(k_copy_pad<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Fe<P>*)in, len, (Fe<P>*)out, n);

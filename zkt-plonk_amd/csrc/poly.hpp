@@ -51,6 +51,10 @@ int poly_set_zero(zkt_ctx* c, void* p, size_t n_elems);
 // optionally clears zero_count elements at zero_at in the same launch (the slack above a transform's output)
 int poly_trim_len(zkt_ctx* c, const void* p, size_t n, uint32_t* d_len, void* zero_at = nullptr, int zero_count = 0);
 int poly_copy_pad(zkt_ctx* c, const void* d_in, size_t len, void* out, size_t n);   // prove.rs:39-55 pad_to
+// prove.rs:49-55 wire_evals: out[i] = values[idx[i]] (0xFFFFFFFF = Variable::Zero), zero padded to n; d_status |= 16 on
+// an index >= n_vars
+int poly_gather_pad(zkt_ctx* c, const void* d_values, size_t n_vars, const uint32_t* d_idx, size_t rows, void* out, size_t n,
+                    uint32_t* d_status);
 int poly_add_blinders(zkt_ctx* c, void* p, const uint32_t* d_len, const void* d_blinders, int k, size_t cap);  // prove.rs:472-483
 int poly_lincomb(zkt_ctx* c, const LinCombArgs& a, void* out, size_t n);
 int poly_eval_many(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results);         // linearization_poly.rs:55-75

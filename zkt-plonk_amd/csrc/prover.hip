@@ -178,6 +178,7 @@ struct Prover {
         uint32_t st = 0;
         ZKT_HIP(c, hipMemcpyAsync(&st, S.status, 4, hipMemcpyDeviceToHost, c->stream));
         ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        if (st & 16u) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "wire index outside the variable map");
         if (st & 4u) return set_err(c, ZKT_ERR_NOT_IN_TABLE, "ElementNotIndexedInTable: a looked-up value is not in the table");
         if (st & 8u) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "combine_split: h1/h2 length differs from n");
         if (st & 2u) return set_err(c, ZKT_ERR_QUOTIENT_TOO_SHORT, "quotient degree exceeds 3n+5: the circuit is not satisfied");
@@ -273,8 +274,30 @@ struct Prover {
 
         // ---- round 1 (prove.rs:116-140) ----
         const uint64_t* wires[3] = {in.a_evals, in.b_evals, in.c_evals};
+        const bool from_vars = in.a_evals == nullptr && in.variables != nullptr;
+        const void* d_vars = in.variables;
+        const uint32_t* d_idx[3] = {in.w_l, in.w_r, in.w_o};
+        if (from_vars) {
+            if (in.n_rows && (!in.w_l || !in.w_r || !in.w_o)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null wire index vector");
+            if (in.n_vars > 0xFFFFFFFEull) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "too many variables");
+            if (!in.wires_on_device) {   // stage the composer's arrays: values in the (still unused) quotient vector
+                if (in.n_vars > 4 * n || 3 * in.n_rows * 4 > (n + 8) * 32)
+                    return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "witness larger than the staging buffers");
+                if (in.n_vars)
+                    ZKT_HIP(c, hipMemcpyAsync(S.qev, in.variables, in.n_vars * 32, hipMemcpyHostToDevice, c->stream));
+                d_vars = S.qev;
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t* dst = (uint32_t*)S.poly[12] + (size_t)k * in.n_rows;   // the round-5 work buffer
+                    if (in.n_rows)
+                        ZKT_HIP(c, hipMemcpyAsync(dst, d_idx[k], in.n_rows * 4, hipMemcpyHostToDevice, c->stream));
+                    d_idx[k] = dst;
+                }
+            }
+        }
         for (int k = 0; k < 3; ++k) {
-            if (in.wires_on_device) {
+            if (from_vars) {
+                if ((rc = poly_gather_pad(c, d_vars, in.n_vars, d_idx[k], in.n_rows, S.ev[k], n, S.status))) return rc;
+            } else if (in.wires_on_device) {
                 if ((rc = poly_copy_pad(c, wires[k], in.n_rows, S.ev[k], n))) return rc;   // prove.rs:39-55 pad_to
             } else {
                 ZKT_HIP(c, hipMemsetAsync(S.ev[k], 0, n * 32, c->stream));
@@ -595,7 +618,8 @@ static void circuit_release(zkt_ctx* c) {
 }
 
 template <class C>
-static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, const size_t* lens) {
+static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, const size_t* lens, bool from_evals = false,
+                          bool from_evals_on_device = false) {
     using R = typename C::Fr;
     using F = Fe<R>;
     if (log_n < 3 || log_n + 2 > R::TWO_ADICITY || log_n + 2 > 27)
@@ -608,12 +632,25 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     S.n = n;
     int rc;
     auto alloc = [&](void** p, size_t elems) { return dev_alloc(c, p, elems * 32); };
+    if ((rc = alloc(&S.qev, 4 * n))) return rc;
     for (int k = 0; k < PK_COUNT; ++k) {
         if (lens[k] > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "prover-key polynomial longer than n");
         if ((rc = alloc(&S.pk[k], n))) return rc;
-        ZKT_HIP(c, hipMemsetAsync(S.pk[k], 0, n * 32, c->stream));
-        if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.pk[k], polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
-        S.pk_len[k] = lens[k];
+        if (from_evals) {
+            // setup.rs:72-90: poly_from_evals of the padded selector / sigma / table-mask evaluations
+            const void* src = polys[k];
+            if (!from_evals_on_device) {
+                ZKT_HIP(c, hipMemsetAsync(S.qev, 0, n * 32, c->stream));   // the quotient vector doubles as staging
+                if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.qev, polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
+                src = S.qev;
+            }
+            if ((rc = ntt_run(c, log_n, 1, 0, src, from_evals_on_device ? lens[k] : n, S.pk[k]))) return rc;
+            S.pk_len[k] = n;
+        } else {
+            ZKT_HIP(c, hipMemsetAsync(S.pk[k], 0, n * 32, c->stream));
+            if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.pk[k], polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
+            S.pk_len[k] = lens[k];
+        }
     }
     for (int k = 0; k < CS_COUNT; ++k) if ((rc = alloc(&S.coset[k], 4 * n))) return rc;
     for (int k = 0; k < 3; ++k) if ((rc = alloc(&S.sigma_ev[k], n))) return rc;
@@ -624,7 +661,6 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     if ((rc = alloc(&S.scan_tmp, 2 * ((n + 8) / 1024 + 4096)))) return rc;
     for (auto& p : S.poly) if ((rc = alloc(&p, n + 8))) return rc;
     for (auto& p : S.wcos) if ((rc = alloc(&p, 4 * n))) return rc;
-    if ((rc = alloc(&S.qev, 4 * n))) return rc;
     const size_t eval_blocks = (n + 8 + 2047) / 2048 + 1;
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
@@ -675,6 +711,31 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     }
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
     c->circuit = st;
+    return ZKT_OK;
+}
+
+// setup.rs:42-166 on the device: polynomials from the evaluation vectors, ExtendedProverKey, the ten commitments
+template <class C>
+static int circuit_setup_t(zkt_ctx* c, int log_n, const uint64_t* const* evals, const size_t* lens, int on_device,
+                           uint64_t* out_commitments, int* out_is_inf) {
+    using Q = typename C::Fq;
+    int rc = circuit_load_t<C>(c, log_n, evals, lens, true, on_device != 0);
+    if (rc) return rc;
+    CircuitState& S = *c->circuit;
+    // setup.rs:104-121: PC::commit of the ten labelled polynomials, ProverKey order; batches of the MSM's slot count
+    const int L = Q::N / 2;
+    for (int k0 = 0; k0 < PK_COUNT; k0 += 5) {
+        for (int k = k0; k < k0 + 5 && k < PK_COUNT; ++k)
+            if ((rc = msm_begin(c, S.pk[k], S.n, 0, 1, k - k0))) return rc;
+        for (int k = k0; k < k0 + 5 && k < PK_COUNT; ++k) {
+            uint64_t xy[12] = {};
+            if ((rc = msm_end(c, k - k0, xy))) return rc;
+            bool inf = true;   // the identity comes back as (0, 0)
+            for (int i = 0; i < 2 * L; ++i) inf = inf && xy[i] == 0;
+            if (out_is_inf) out_is_inf[k] = inf ? 1 : 0;
+            for (int i = 0; i < 2 * L; ++i) out_commitments[(size_t)k * 2 * L + i] = xy[i];
+        }
+    }
     return ZKT_OK;
 }
 
@@ -794,6 +855,17 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
     if (proof.size() > cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "proof buffer too small");
     memcpy(out, proof.data(), proof.size());
     return ZKT_OK;
+}
+
+int zkt_circuit_setup(zkt_ctx* c, int log_n, const uint64_t* const* evals, const size_t* eval_lens, int evals_on_device,
+                      uint64_t* out_commitments, int* out_is_infinity) {
+    if (!c || !evals || !eval_lens || !out_commitments) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    (void)hipSetDevice(c->device);
+    if (log_n < 3 || log_n > 26) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "circuit bound out of range");
+    if (c->curve == ZKT_CURVE_BN254)
+        return circuit_setup_t<Bn254Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
+    return circuit_setup_t<Bls381Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
 }
 
 int zkt_prove(zkt_ctx* c, const zkt_prove_inputs* in, zkt_transcript* tr, uint8_t* proof_out, size_t proof_cap,

@@ -27,11 +27,21 @@ def seed_transcript(tr: Transcript, n: int, vk_commits: Dict[str, Optional[tuple
 class GpuProver:
     """Device-resident circuit + SRS; one instance per (circuit, context)."""
 
-    def __init__(self, ctx: Context, log_n: int, pk_polys: Dict[str, np.ndarray]):
+    def __init__(self, ctx: Context, log_n: int, pk_polys: Dict[str, np.ndarray] = None):
         self.ctx = ctx
         self.log_n = log_n
         self.n = 1 << log_n
-        ctx.circuit_load(log_n, [pk_polys[k] for k in PK_ORDER])
+        if pk_polys is not None:
+            ctx.circuit_load(log_n, [pk_polys[k] for k in PK_ORDER])
+
+    @classmethod
+    def setup(cls, ctx: Context, log_n: int, evals: Dict[str, np.ndarray]):
+        """proof_system::setup (plonk-core/src/proof_system/setup.rs:42-166) on the device, from the SetupComposer's
+        ten evaluation vectors.  -> (prover, {name: (xy limbs, is_infinity)}) : the loaded prover and the VerifierKey
+        commitments."""
+        self = cls(ctx, log_n, None)
+        pts, inf = ctx.circuit_setup(log_n, [evals[k] for k in PK_ORDER])
+        return self, {k: (pts[i], bool(inf[i])) for i, k in enumerate(PK_ORDER)}
 
     def prove(self, a, b, c, table, public_inputs: Dict[int, np.ndarray], blinders, transcript: Transcript) -> bytes:
         pos = sorted(public_inputs.keys())
