@@ -110,11 +110,17 @@ ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
     const Fx<Q> ppp = mul(pp_, pp);
     const Fx<Q> qq = mul(p.x, pp);
     XyzzX<Q> r;
-    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(rr2, ppp), fx_dbl<Q>(qq));                   // < 8p
     if (INL) {
-        // 6p * 10p + 4p * 2p < R' p ; < 2p
-        r.y = fx_mul2_inl<Q>(rr, fx_sub<Q, 8>(qq, r.x), fx_sub<Q, 4>(fx_zero<Q>(), p.y), ppp);
+        r.x = fx_sub2<Q, 6>(rr2, ppp, qq);                                       // rr2 + 6p - ppp - 2 qq < 8p
+        // Y3 = R (Q - X3) - Y1 PPP as one double product.  (Q + 9p - X3) < 11p, (5p - Y1) < 5p:
+        // 6p * 11p + 5p * 2p < R' p ; result < 2p.  With nine limbs the two differences skip their carry pass
+        // (limbs <= 3 * 2^29: the 27 column terms stay below 63 * 2^58); fourteen limbs would overflow the column.
+        if constexpr (FxP<Q>::L <= 9)
+            r.y = fx_mul2_inl<Q>(rr, fx_sub_lazy<Q, 9>(qq, r.x), ppp, fx_sub_lazy<Q, 5>(fx_zero<Q>(), p.y));
+        else
+            r.y = fx_mul2_inl<Q>(rr, fx_sub<Q, 8>(qq, r.x), ppp, fx_sub<Q, 4>(fx_zero<Q>(), p.y));
     } else {
+        r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(rr2, ppp), fx_dbl<Q>(qq));               // < 8p
         r.y = fx_sub<Q, 2>(mul(rr, fx_sub<Q, 8>(qq, r.x)), mul(p.y, ppp));       // 6p * 10p ; < 4p
     }
     r.zz = mul(p.zz, pp);

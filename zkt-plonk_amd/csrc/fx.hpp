@@ -277,6 +277,24 @@ ZKT_HD Fx<P> fx_sub_lazy(const Fx<P>& a, const Fx<P>& b) {
     return r;
 }
 
+// a + K p - b - 2c in one carry pass (b + 2c <= K p); result normalised, value < a + K p
+template <class P, int K>
+ZKT_HD Fx<P> fx_sub2(const Fx<P>& a, const Fx<P>& b, const Fx<P>& c2) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        // |x| < 2^29 + 2^29 + 2^30 + 2^29: fits a signed 32-bit limb
+        int32_t x = (int32_t)a.l[i] - (int32_t)b.l[i] - (int32_t)(c2.l[i] << 1) + (int32_t)FxP<P>::kmod(K, i) + c;
+        r.l[i] = (uint32_t)x & FxP<P>::MASK;
+        c = x >> 29;
+    }
+    int32_t x = (int32_t)a.l[L - 1] - (int32_t)b.l[L - 1] - (int32_t)(c2.l[L - 1] << 1) + (int32_t)FxP<P>::kmod(K, L - 1) + c;
+    r.l[L - 1] = (uint32_t)x;
+    return r;
+}
+
 template <class P>
 ZKT_HD Fx<P> fx_dbl(const Fx<P>& a) { return fx_add<P>(a, a); }
 
