@@ -461,16 +461,20 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
     }
     uint32_t end = offsets[cur + 1];
     XyzzX<Q> acc = xx_identity<Q>();
+    // two-deep software pipeline: the index of pair p+2 and the point of pair p+1 are fetched behind the addition of
+    // pair p, so that no load in the loop waits for another load
     uint32_t v = vals[p0];
+    uint32_t v1 = (p0 + 1 < p1) ? vals[p0 + 1] : 0u;
     Fe<Q> nx = fe_load<Q>(&table[v & 0x7fffffffu].x), ny = fe_load<Q>(&table[v & 0x7fffffffu].y);
     for (uint32_t p = (uint32_t)p0; p < p1; ++p) {
         const uint32_t vcur = v;
         const Fe<Q> cx = nx, cy = ny;
-        if (p + 1 < p1) {  // prefetch the next gathered point behind this addition
-            v = vals[p + 1];
+        v = v1;
+        if (p + 1 < p1) {
             nx = fe_load<Q>(&table[v & 0x7fffffffu].x);
             ny = fe_load<Q>(&table[v & 0x7fffffffu].y);
         }
+        if (p + 2 < p1) v1 = vals[p + 2];
         if (p == end) {    // next non-empty bucket
             xx_store<Q>(pieces + (size_t)t + cur, acc);
             acc = xx_identity<Q>();
