@@ -192,6 +192,52 @@ ZKT_D void xx_store(Xyzz<Q>* p, const XyzzX<Q>& a) {
     fe_store<Q>(&p->zz, fx_pack<Q>(fx_canon<Q>(a.zz)));
     fe_store<Q>(&p->zzz, fx_pack<Q>(fx_canon<Q>(a.zzz)));
 }
+// Raw form: the 4 L limbs as they are (lazily reduced, bounds of XyzzX), all-zero = identity.  For intermediate
+// sums that are read back once (the MSM's per-chunk pieces): no reduction, no packing on either side.
+template <class Q>
+struct alignas(16) XyzzRaw {
+    uint32_t l[4 * FxP<Q>::L];
+};
+template <class Q>
+ZKT_D void xx_store_raw(XyzzRaw<Q>* p, const XyzzX<Q>& a) {
+    constexpr int L = FxP<Q>::L;
+    static_assert((4 * L) % 4 == 0, "whole 16-byte words");
+    uint32_t w[4 * L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        w[i] = a.inf ? 0u : a.x.l[i];
+        w[L + i] = a.inf ? 0u : a.y.l[i];
+        w[2 * L + i] = a.inf ? 0u : a.zz.l[i];
+        w[3 * L + i] = a.inf ? 0u : a.zzz.l[i];
+    }
+    uint4* d = reinterpret_cast<uint4*>(p->l);
+#pragma unroll
+    for (int i = 0; i < L; ++i) d[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class Q>
+ZKT_D XyzzX<Q> xx_load_raw(const XyzzRaw<Q>* p) {
+    constexpr int L = FxP<Q>::L;
+    uint32_t w[4 * L];
+    const uint4* s = reinterpret_cast<const uint4*>(p->l);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const uint4 v = s[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    XyzzX<Q> r;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        r.x.l[i] = w[i];
+        r.y.l[i] = w[L + i];
+        r.zz.l[i] = w[2 * L + i];
+        r.zzz.l[i] = w[3 * L + i];
+        any |= w[2 * L + i];
+    }
+    r.inf = any == 0;
+    return r;
+}
+
 // R' form -> arkworks R form (canonical packed), for the one point that leaves the MSM
 template <class Q>
 ZKT_D void xx_store_ark(Xyzz<Q>* p, const XyzzX<Q>& a) {

@@ -60,7 +60,7 @@ struct MsmState {
     uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
     uint32_t l2_items = 0;                         // upper bound of level-2 tiles
     uint32_t* offsets = nullptr;  // B + 2
-    void* pieces = nullptr;       // Xyzz[max_chunks + B + 2]
+    void* pieces = nullptr;       // XyzzRaw[max_chunks + B + 2]
     // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
     // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
     static constexpr int SLOTS = 6;
@@ -442,7 +442,7 @@ template <class C>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, uint32_t chunk,
                                                         const uint32_t* offsets,
                                                         const Affine<typename C::Fq>* table,
-                                                        Xyzz<typename C::Fq>* pieces) {
+                                                        XyzzRaw<typename C::Fq>* pieces) {
     using Q = typename C::Fq;
     const uint32_t base = offsets[1], m = offsets[B + 1];   // first / one past the last pair with a non-zero bucket
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,7 +459,10 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
         }
         cur = lo;
     }
+    // end of the current bucket and of the next one: the second is fetched a whole bucket ahead, so that moving on
+    // to the next bucket does not wait for memory (only runs of empty buckets do)
     uint32_t end = offsets[cur + 1];
+    uint32_t end2 = offsets[(cur + 2 <= B + 1) ? cur + 2 : B + 1];
     XyzzX<Q> acc = xx_identity<Q>();
     // two-deep software pipeline: the index of pair p+2 and the point of pair p+1 are fetched behind the addition of
     // pair p, so that no load in the loop waits for another load
@@ -476,11 +479,12 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
         }
         if (p + 2 < p1) v1 = vals[p + 2];
         if (p == end) {    // next non-empty bucket
-            xx_store<Q>(pieces + (size_t)t + cur, acc);
+            xx_store_raw<Q>(pieces + (size_t)t + cur, acc);
             acc = xx_identity<Q>();
             do {
                 ++cur;
-                end = offsets[cur + 1];
+                end = end2;
+                end2 = offsets[(cur + 2 <= B + 1) ? cur + 2 : B + 1];
             } while (end <= p);
         }
         if (!(fe_is_zero<Q>(cx) && fe_is_zero<Q>(cy))) {
@@ -491,12 +495,12 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
             acc = xx_add_mixed<Q, true>(acc, q);
         }
     }
-    xx_store<Q>(pieces + (size_t)t + cur, acc);
+    xx_store_raw<Q>(pieces + (size_t)t + cur, acc);
 }
 
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B, uint32_t chunk,
-                                                        const Xyzz<typename C::Fq>* pieces,
+                                                        const XyzzRaw<typename C::Fq>* pieces,
                                                         Xyzz<typename C::Fq>* buckets, uint32_t* heavy) {
     using Q = typename C::Fq;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..B ; bucket 0 is the identity
@@ -511,12 +515,8 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets,
                 heavy[1 + atomicAdd(heavy, 1u)] = b;
                 return;
             }
-            if (t1 == t0) {  // a single piece: plain copy
-                xyzz_store<Q>(buckets + b, xyzz_load<Q>(pieces + (size_t)t0 + b));
-                return;
-            }
-            acc = xx_load<Q>(pieces + (size_t)t0 + b);
-            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xx_add<Q>(acc, xx_load<Q>(pieces + (size_t)t + b));
+            acc = xx_load_raw<Q>(pieces + (size_t)t0 + b);
+            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xx_add<Q>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
         }
     }
     xx_store<Q>(buckets + b, acc);
@@ -559,7 +559,7 @@ ZKT_D XyzzX<Q> block_sum_256(XyzzX<Q> acc, Xyzz<Q>* wsum) {
 // crowded buckets (skewed digit distributions): one block folds all pieces of one bucket
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, uint32_t chunk,
-                                                   const Xyzz<typename C::Fq>* pieces,
+                                                   const XyzzRaw<typename C::Fq>* pieces,
                                                    Xyzz<typename C::Fq>* buckets, const uint32_t* heavy) {
     using Q = typename C::Fq;
     __shared__ Xyzz<Q> wsum[4];
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, uint
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
         XyzzX<Q> acc = xx_identity<Q>();
-        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xx_add<Q>(acc, xx_load<Q>(pieces + (size_t)t + b));
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xx_add<Q>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
         acc = block_sum_256<Q>(acc, wsum);
         if (threadIdx.x == 0) xx_store<Q>(buckets + b, acc);
     }
@@ -717,7 +717,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->nb1 * 256 + 2) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
     size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
-    if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(Xyzz<Q>)))) return rc;
+    if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
     size_t nseg = st->B / MSM_SEG;
     {
         int blocks_per_cu = 0, cus = 0;
@@ -870,16 +870,16 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + chunk - 1) / chunk;
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.vals2,
-                           st.B, chunk, st.offsets, (const Affine<Q>*)st.table, (Xyzz<Q>*)st.pieces);
+                           st.B, chunk, st.offsets, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
     // the slot's tail buffers may still be read by the previous MSM that used this slot
     if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
     hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
-                       chunk, (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
+                       chunk, (const XyzzRaw<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, c->stream, st.offsets, chunk,
-                       (const Xyzz<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
+                       (const XyzzRaw<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
     ZKT_HIP(c, hipGetLastError());
     }
     // ---- tail on the side stream: overlaps whatever the main stream does next ----
