@@ -131,6 +131,11 @@ void zkt_transcript_append_scalars(zkt_transcript* t, const char* label, const u
 void zkt_transcript_append_commitment(zkt_transcript* t, const char* label, const uint8_t* x_le, const uint8_t* y_le,
                                       size_t fq_bytes, int is_infinity);                      /* transcript.rs:81-86 */
 void zkt_transcript_challenge_scalar(zkt_transcript* t, const char* label, int fr_bits, uint8_t out_le32[32]); /* :101-108 */
+/* VerifierKey::seed_transcript (proof_system/keys/mod.rs:260-275) in one call: circuit_size, then the ten commitments
+ * q_m q_l q_r q_o q_c sigma1 sigma2 sigma3 q_lookup q_table under their "<name>_commit" labels.  xy_le: 10 x (x, y),
+ * fq_bytes little-endian canonical bytes per coordinate; is_infinity: 10 flags (may be NULL = none). */
+void zkt_transcript_seed(zkt_transcript* t, uint64_t circuit_size, const uint8_t* xy_le, const uint8_t* is_infinity,
+                         size_t fq_bytes);
 /* raw merlin access (conformance vectors); ZKT_ERR_INVALID_ARGUMENT on a non-merlin transcript */
 int zkt_transcript_append_message(zkt_transcript* t, const char* label, const uint8_t* msg, size_t len);
 int zkt_transcript_challenge_bytes(zkt_transcript* t, const char* label, uint8_t* out, size_t len);

@@ -116,6 +116,8 @@ def _bind_prover(L):
     L.zkt_transcript_append_commitment.restype = None
     L.zkt_transcript_challenge_scalar.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, u8p]
     L.zkt_transcript_challenge_scalar.restype = None
+    L.zkt_transcript_seed.argtypes = [vp, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.zkt_transcript_seed.restype = None
     L.zkt_transcript_append_message.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     L.zkt_transcript_challenge_bytes.argtypes = [vp, ctypes.c_char_p, u8p, ctypes.c_size_t]
     L.zkt_circuit_load.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64p_), ctypes.POINTER(ctypes.c_size_t)]
@@ -161,6 +163,15 @@ class Transcript:
         else:
             self._L.zkt_transcript_append_commitment(self._h, label.encode(), int(point[0]).to_bytes(nb, "little"),
                                                      int(point[1]).to_bytes(nb, "little"), nb, 0)
+
+    def seed(self, circuit_size: int, points):
+        """VerifierKey::seed_transcript (keys/mod.rs:260-275) in one call; points: the ten commitments in ProverKey
+        order, affine canonical ints or None (identity)."""
+        nb = self.fq_bytes
+        buf = b"".join(bytes(2 * nb) if p is None else int(p[0]).to_bytes(nb, "little") + int(p[1]).to_bytes(nb, "little")
+                       for p in points)
+        inf = bytes(1 if p is None else 0 for p in points)
+        self._L.zkt_transcript_seed(self._h, circuit_size, buf, inf, nb)
 
     def challenge_scalar(self, label: str) -> int:
         out = (ctypes.c_uint8 * 32)()

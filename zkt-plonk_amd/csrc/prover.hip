@@ -4,6 +4,9 @@
 // two scalars (the grand-product denominators) cross PCIe, for the host-side Fiat-Shamir transcript.
 #include "ctx.hpp"
 #include "hostinv.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "ec.hpp"
 #include "poly.hpp"
 #include "transcript.hpp"
@@ -119,7 +122,22 @@ struct Prover {
     zkt_ctx* c;
     CircuitState& S;
     HostTranscript& tr;
-    Prover(zkt_ctx* ctx, CircuitState& st, HostTranscript& t) : c(ctx), S(st), tr(t) {}
+    Prover(zkt_ctx* ctx, CircuitState& st, HostTranscript& t) : c(ctx), S(st), tr(t) {
+        trace_on = getenv("ZKT_HOST_TRACE") != nullptr;
+    }
+    // ZKT_HOST_TRACE=1: wall-clock marks of the host control path (where the GPU may be waiting for the host)
+    bool trace_on = false;
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+    void mark(const char* what) {
+        if (trace_on) marks.emplace_back(what, std::chrono::steady_clock::now());
+    }
+    void dump_marks() {
+        if (!trace_on || marks.empty()) return;
+        for (size_t i = 1; i < marks.size(); ++i)
+            fprintf(stderr, "[zkt host] %-28s %8.1f us\n", marks[i].first,
+                    std::chrono::duration<double, std::micro>(marks[i].second - marks[i - 1].second).count());
+        marks.clear();
+    }
 
     void tr_commit(const char* label, const Affine<Q>& p) {
         uint8_t x[64], y[64];
@@ -273,6 +291,7 @@ struct Prover {
         }
 
         // ---- round 1 (prove.rs:116-140) ----
+        mark("start");
         const uint64_t* wires[3] = {in.a_evals, in.b_evals, in.c_evals};
         const bool from_vars = in.a_evals == nullptr && in.variables != nullptr;
         const void* d_vars = in.variables;
@@ -336,10 +355,13 @@ struct Prover {
         for (int k : {W_A, W_B, W_C}) if ((rc = to_coset(k))) return rc;
         if (!S.t_coset_valid && (rc = to_coset(W_T))) return rc;   // unchanged table: its coset is still resident
         for (int k : {W_H1, W_H2}) if ((rc = to_coset(k))) return rc;
+        mark("enqueue rounds 1+2");
         for (int k = 0; k < 3; ++k) {
             if ((rc = commit_end(k, &cm[k]))) return rc;
+            if (k == 0) mark("wait a_commit");
             tr_commit(L1[k], cm[k]);
         }
+        mark("b c commits");
         if (!same_table) {
             if ((rc = commit_end(3, &cm[3]))) return rc;
             memcpy(S.t_commit_xy, cm[3].x.v, Q::N * 4);
@@ -354,6 +376,7 @@ struct Prover {
         tr_commit("t_commit", cm[3]);
         tr_commit("h1_commit", cm[4]);
         tr_commit("h2_commit", cm[5]);
+        mark("t h1 h2 commits");
 
         // ---- round 3 (prove.rs:190-255) ----
         const F beta = tr_challenge("beta"), gamma = tr_challenge("gamma"), delta = tr_challenge("delta"),
@@ -373,6 +396,7 @@ struct Prover {
         // host round trip (the second pair borrows the still unused z1 coset buffer).
         void* pn2 = S.wcos[W_Z1];
         void* sd2 = (char*)S.wcos[W_Z1] + n * 32;
+        mark("challenges round 3");
         if ((rc = z1_terms(c, za))) return rc;
         if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;   // PN
         if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;    // SD
@@ -381,7 +405,9 @@ struct Prover {
         if ((rc = scan_mul(c, S.sc[1], sd2, n, true, S.scan_tmp))) return rc;
         ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
         ZKT_HIP(c, hipMemcpyAsync(pin + 1, sd2, 32, hipMemcpyDeviceToHost, c->stream));
+        mark("enqueue grand products");
         if ((rc = check_status())) return rc;   // synchronises; reports a lookup outside the table (round 2)
+        mark("wait grand products");
         if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the permutation grand product");
         if (fe_is_zero<R>(pin[1])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the lookup grand product");
         {
@@ -420,6 +446,7 @@ struct Prover {
         for (int k = 0; k < 2; ++k) if ((rc = commit_end(k, &cm[6 + k]))) return rc;
         tr_commit("z1_commit", cm[6]);
         tr_commit("z2_commit", cm[7]);
+        mark("round 3 finish + commits");
 
         // ---- round 4 (prove.rs:258-313) ----
         const F alpha = tr_challenge("alpha");
@@ -449,6 +476,7 @@ struct Prover {
         tr_commit("q_lo_commit", cm[8]);
         tr_commit("q_mid_commit", cm[9]);
         tr_commit("q_hi_commit", cm[10]);
+        mark("round 4");
 
         // ---- round 5 (prove.rs:318-451, linearization_poly.rs:19-121) ----
         const F xi = tr_challenge("xi");
@@ -475,7 +503,9 @@ struct Prover {
         void* d_results = (char*)S.small + 32 * 32;
         if ((rc = poly_eval_many(c, ea, d_partials, d_results))) return rc;
         ZKT_HIP(c, hipMemcpyAsync(pin, d_results, 12 * 32, hipMemcpyDeviceToHost, c->stream));
+        mark("enqueue evaluations");
         if ((rc = check_status())) return rc;   // synchronises the stream
+        mark("wait evaluations");
         F ev[12];
         for (int k = 0; k < 12; ++k) ev[k] = pin[k];
         const F &e_a = ev[0], &e_b = ev[1], &e_c = ev[2], &e_s1 = ev[3], &e_s2 = ev[4], &e_z1n = ev[5], &e_ql = ev[6],
@@ -592,6 +622,8 @@ struct Prover {
             H::to_le_bytes(ev[k], b);
             proof.insert(proof.end(), b, b + 32);
         }
+        mark("round 5 finish");
+        dump_marks();
         return ZKT_OK;
     }
 };
@@ -813,6 +845,16 @@ void zkt_transcript_append_scalars(zkt_transcript* t, const char* label, const u
 void zkt_transcript_append_commitment(zkt_transcript* t, const char* label, const uint8_t* x_le, const uint8_t* y_le,
                                       size_t fq_bytes, int is_infinity) {
     t->impl->append_commitment(label, x_le, y_le, fq_bytes, is_infinity != 0);
+}
+void zkt_transcript_seed(zkt_transcript* t, uint64_t circuit_size, const uint8_t* xy_le, const uint8_t* is_infinity,
+                         size_t fq_bytes) {
+    static const char* labels[10] = {"q_m_commit", "q_l_commit", "q_r_commit", "q_o_commit", "q_c_commit",
+                                     "sigma1_commit", "sigma2_commit", "sigma3_commit", "q_lookup_commit", "q_table_commit"};
+    t->impl->append_u64("circuit_size", circuit_size);
+    for (int k = 0; k < 10; ++k) {
+        const uint8_t* x = xy_le + (size_t)k * 2 * fq_bytes;
+        t->impl->append_commitment(labels[k], x, x + fq_bytes, fq_bytes, is_infinity && is_infinity[k]);
+    }
 }
 void zkt_transcript_challenge_scalar(zkt_transcript* t, const char* label, int fr_bits, uint8_t out_le32[32]) {
     t->impl->challenge_scalar(label, (size_t)fr_bits, out_le32);

@@ -18,9 +18,7 @@ NUM_BLINDERS = 19  # a(2) b(2) c(2) h1(3) h2(2) z1(3) z2(3) b0 b1 -- prove.rs:12
 
 def seed_transcript(tr: Transcript, n: int, vk_commits: Dict[str, Optional[tuple]]) -> Transcript:
     """keys/mod.rs:260-275; vk_commits maps the PK_ORDER names to affine points (canonical ints) or None."""
-    tr.append_u64("circuit_size", n)
-    for name in PK_ORDER:
-        tr.append_commitment(name + "_commit", vk_commits[name])
+    tr.seed(n, [vk_commits[name] for name in PK_ORDER])
     return tr
 
 
