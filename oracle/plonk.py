@@ -509,6 +509,32 @@ class Proof:  # proof_system/proof.rs:106-155
         return bytes(out)
 
 
+def proof_deserialize(cv: Curve, data: bytes) -> Proof:
+    """Inverse of Proof.serialize (proof_system/proof.rs:98-155): 11 compressed G1, 2 x (compressed G1 || 0x00),
+    12 Fr little-endian."""
+    nb = (cv.fq.bits + 2 + 7) // 8
+    fb = cv.fr.limbs64 * 8
+    assert len(data) == 13 * nb + 2 + 12 * fb, "proof length"
+    pos = 0
+    commits = {}
+    for k in Proof.COMMIT_ORDER:
+        commits[k] = C.point_deserialize_compressed(cv, data[pos:pos + nb])
+        pos += nb
+    opens = []
+    for _ in range(2):
+        opens.append(C.point_deserialize_compressed(cv, data[pos:pos + nb]))
+        pos += nb
+        assert data[pos] == 0, "kzg10::Proof::random_v must be None"
+        pos += 1
+    ev = ProofEvaluations()
+    for k in ProofEvaluations.ORDER:
+        v = int.from_bytes(data[pos:pos + fb], "little")
+        assert v < cv.fr.p, "non-canonical evaluation"
+        setattr(ev, k, v)
+        pos += fb
+    return Proof(commits, opens[0], opens[1], ev)
+
+
 def linearization(cv: Curve, dom: Domain, pk: ProverKey, ch, xi, polys):
     """proof_system/linearization_poly.rs:19-121 with keys/arithmetic.rs:37-46,
     keys/permutation.rs:34-69, keys/lookup.rs:29-65."""

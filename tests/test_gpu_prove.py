@@ -162,6 +162,54 @@ def test_witness_gather_on_the_device(ctxs):
     assert e.value.code == 1
 
 
+def test_full_size_proof_is_accepted_by_the_verifier(ctxs):
+    """BASELINE.json configs[1] (BN254, n = 2^20, TABLE_SIZE 1024, 7 public inputs): the workload bench.py times.
+    The oracle cannot prove at this size in test time, so the pin is size independent: the oracle's verifier
+    (proof.rs:285-503, pairing replaced by the trapdoor identity) accepts the GPU proof under the GPU-made VerifierKey,
+    one of whose commitments is checked against the CPU oracle; a flipped evaluation is rejected."""
+    import zkt_plonk_amd as z
+    import bench as B
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    fld = B.FIELDS[cv.name]
+    log_n, n = 20, 1 << 20
+    tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
+    ctx.srs_generate(tau, n + 8)
+    circ = B.synthetic_circuit(fld, log_n)
+    evals = {name: K.fr_to_mont(cv, circ["sel"][name]) for name in z.PK_ORDER}
+    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    L = cv.fq.limbs64
+    q = cv.fq.p
+    rinv = pow(1 << (64 * L), -1, q)
+    pts = {}
+    for name in z.PK_ORDER:
+        xy, inf = commits[name]
+        pts[name] = None if inf else (sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % q,
+                                      sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % q)
+    # one VerifierKey commitment against the CPU port: q_c = commit(ifft(q_c evaluations))
+    srs = ctx.srs_download(0, n)
+    coeffs = K.ntt_mont(cv, log_n, True, False, evals["q_c"])
+    want, winf = K.msm_mont(cv, srs, coeffs)
+    assert not winf and np.array_equal(commits["q_c"][0], want)
+    gates = circ["gates"]
+    pi_pos = sorted(circ["pi"])
+    blinders = field_elems(cv.fr.p, 2020, P.NUM_BLINDERS)
+    tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * L)
+    z.seed_transcript(tr, n, pts)
+    proof = ctx.prove(K.fr_to_mont(cv, circ["a"][:gates]), K.fr_to_mont(cv, circ["b"][:gates]),
+                      K.fr_to_mont(cv, circ["c"][:gates]), K.fr_to_mont(cv, circ["table"]), pi_pos,
+                      K.fr_to_mont(cv, [circ["pi"][k] for k in pi_pos]), K.fr_to_mont(cv, blinders), tr)
+    assert len(proof) == 802
+    dom = P.Domain(cv.fr, n)
+    w = dom.group_gen
+    vk = P.VerifierKey(n, [pow(w, i, cv.fr.p) for i in pi_pos], pts)
+    pis = [circ["pi"][k] for k in pi_pos]
+    assert P.verify(cv, tau, vk, P.proof_deserialize(cv, proof), P.new_seeded_transcript(cv, vk), pis)
+    bad = bytearray(proof)
+    bad[-40] ^= 1                                   # inside the last evaluation (h2_eval)
+    assert not P.verify(cv, tau, vk, P.proof_deserialize(cv, bytes(bad)), P.new_seeded_transcript(cv, vk), pis)
+
+
 def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
     """Second and third proof on the same loaded circuit take the cached-table path (same table), then a
     different table invalidates the cache; every proof must still equal the oracle's bytes."""

@@ -103,6 +103,11 @@ def test_full_prove_verify_and_golden_bytes(cv, golden):
     assert {k: "%x" % v for k, v in tr.challenges.items()} == g["challenges"]
     assert P.verify(cv, tau, vk, proof, P.new_seeded_transcript(cv, vk), [10, 2])
     assert not P.verify(cv, tau, vk, proof, P.new_seeded_transcript(cv, vk), [10, 3])
+    # the wire format parses back to the same proof (decompression picks y by the sign flag)
+    back = P.proof_deserialize(cv, data)
+    assert back.commits == proof.commits and back.aw_opening == proof.aw_opening
+    assert back.saw_opening == proof.saw_opening and back.evaluations == proof.evaluations
+    assert back.serialize(cv) == data
     # tampering with an evaluation must be rejected
     proof.evaluations.a = (proof.evaluations.a + 1) % cv.fr.p
     assert not P.verify(cv, tau, vk, proof, P.new_seeded_transcript(cv, vk), [10, 2])
