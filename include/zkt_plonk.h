@@ -221,6 +221,10 @@ int zkt_debug_params(zkt_ctx* ctx, int which, uint32_t* out, size_t out_words);
  * 4: a^-1 (host binary GCD); 5: a^-1 (the kernels' Fermat ladder); 6: a^2 + b^2 through the double product and
  * the squaring kernel; 7: (a - b) * b through the carry-free difference. */
 int zkt_host_field_op(int curve_id, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
+/* Sum of `count` affine G1 points on the HOST (x, y arkworks Montgomery limbs each; (0, 0) = identity): the combine
+ * step of an MSM whose points are sharded across GPUs by index range (the partial sums are
+ * all-gathered as raw bytes - no collective can reduce curve points - and added locally).  No context needed. */
+int zkt_g1_sum_host(int curve_id, const uint64_t* points_xy_mont, size_t count, uint64_t* out_xy_mont, int* out_is_infinity);
 /* Elementwise Fr product on the device (out[i] = a[i]*b[i], Montgomery); test hook for the field
  * kernels. Host pointers. */
 int zkt_debug_fr_mul(zkt_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);

@@ -146,6 +146,31 @@ def test_msm_skewed_digit_distributions(shape, ctxs):
     assert inf == winf and np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_msm_sharded_by_index_range(cv, shards, ctxs):
+    """SURVEY.md section 8e "MSM - one tiny exchange": the partial sums over contiguous index ranges (what each GPU
+    of a node would compute over its SRS slice), combined by the host-side point sum that follows the all-gather,
+    equal the single-GPU MSM and the oracle."""
+    from zkt_plonk_amd._lib import g1_sum_host
+    from zkt_plonk_amd.parallel import shard_range
+    ctx = ctxs[cv.name]
+    n = 5000
+    ctx.srs_generate(0x8E + shards, n)
+    srs = ctx.srs_download(0, n)
+    rng = np.random.default_rng(shards)
+    sc = rand_fr(rng, n)
+    full, finf = ctx.msm(sc)
+    parts = []
+    for r in range(shards):
+        lo, hi = shard_range(n, r, shards)
+        xy, inf = ctx.msm(sc[lo:hi], base_offset=lo)
+        parts.append(np.zeros_like(xy) if inf else xy)
+    got, ginf = g1_sum_host(cv.name, np.stack(parts))
+    want, winf = K.msm_mont(cv, srs, sc)
+    assert ginf == finf == winf and np.array_equal(got, full) and np.array_equal(got, want)
+
+
 def test_msm_full_size_2_20(ctxs):
     """BASELINE config 3: 2^20 scalars/points, bit-exact commitment (BN254), plus linearity."""
     cv = F.BN254

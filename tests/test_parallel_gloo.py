@@ -56,6 +56,79 @@ def test_world_size_two_sharding_and_timing():
     assert all(r[4] == list(range(7)) and r[5] for r in res)   # global unit order on every rank
 
 
+def _msm_worker(rank, world, port, q):
+    """Index-range-sharded MSM: each rank's partial sum comes from the CPU oracle here (the test has no GPU); the
+    exchange and the host-side point addition are the product's."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    import importlib
+    par = importlib.import_module("zkt_plonk_amd.parallel")
+    from oracle import coracle as K, fields as F
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cv = F.BN254
+        n = 1000
+        srs = K.srs_mont(cv, 0xFEED, n)
+        rng = np.random.default_rng(11)
+        sc = rng.integers(0, 1 << 61, size=(n, 4), dtype=np.uint64)
+        sc[:, 3] &= (1 << 60) - 1
+        lo, hi = par.shard_range(n, rank, world)
+        part, pinf = K.msm_mont(cv, srs[lo:hi], sc[lo:hi], True)          # this rank's slice of points and scalars
+        total, tinf = par.sharded_msm_combine(dist, "bn254", part, pinf)
+        want, winf = K.msm_mont(cv, srs, sc, True)
+        # an all-identity contribution must be neutral
+        zero, zinf = par.sharded_msm_combine(dist, "bn254", part, True)
+        q.put((rank, bool(tinf == winf and np.array_equal(total, want)), bool(zinf)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_two_sharded_msm_combine():
+    sys.path.insert(0, ROOT)
+    import zkt_plonk_amd  # noqa: F401
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_msm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res)
+
+
+def test_g1_sum_host_matches_oracle():
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd._lib import g1_sum_host
+    from oracle import coracle as K, fields as F, curve as C
+    for cv in (F.BN254, F.BLS12_381):
+        srs = K.srs_mont(cv, 0xBEEF, 9)
+        pts = K.points_from_mont(cv, srs)
+        acc = None
+        for P_ in pts:
+            acc = C.add(cv, acc, P_)
+        out, inf = g1_sum_host(cv.name, srs)
+        assert not inf and K.points_from_mont(cv, out.reshape(1, -1))[0] == acc
+        # P + (-P) and the empty sum are the identity; a doubled point takes the doubling path
+        neg = srs[:1].copy()
+        L = cv.fq.limbs64
+        y = sum(int(v) << (64 * i) for i, v in enumerate(neg[0, L:]))
+        ny = (cv.fq.p - y) % cv.fq.p
+        neg[0, L:] = [(ny >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(L)]
+        assert g1_sum_host(cv.name, np.vstack([srs[:1], neg]))[1]
+        assert g1_sum_host(cv.name, np.zeros((0, 2 * L), dtype=np.uint64))[1]
+        out, inf = g1_sum_host(cv.name, np.vstack([srs[1:2], srs[1:2]]))
+        assert K.points_from_mont(cv, out.reshape(1, -1))[0] == C.add(cv, pts[1], pts[1])
+
+
 def test_shard_range_covers_everything():
     import importlib
     sys.path.insert(0, ROOT)

@@ -126,6 +126,24 @@ def _bind_prover(L):
     L.zkt_prove.argtypes = [vp, ctypes.POINTER(ProveInputs), vp, u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
 
 
+def g1_sum_host(curve, points) -> tuple:
+    """Host sum of affine G1 points ((count, 2*fq_limbs) Montgomery limbs, (0,0) = identity) -> (xy limbs, is_infinity).
+    The combine step of an index-range-sharded MSM; needs no GPU context."""
+    L = lib()
+    cid = CURVE_BN254 if curve in ("bn254", CURVE_BN254) else CURVE_BLS12_381
+    limbs = 4 if cid == CURVE_BN254 else 6
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 2 * limbs)
+    out = np.zeros(2 * limbs, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    L.zkt_g1_sum_host.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t,
+                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+    rc = L.zkt_g1_sum_host(cid, u64p(pts) if pts.size else ctypes.POINTER(ctypes.c_uint64)(), pts.shape[0], u64p(out),
+                           ctypes.byref(inf))
+    if rc:
+        raise ZktError(rc, "zkt_g1_sum_host")
+    return out, bool(inf.value)
+
+
 class Transcript:
     """Built-in host transcript (T: TranscriptProtocol): kind 'merlin' (plonk-core/src/transcript.rs:46-109)
     or 'ethereum' (gadgets/src/transcript.rs:8-90).  Scalars / coordinates are canonical integers."""

@@ -1,6 +1,7 @@
 // C-ABI entry points: context, memory plumbing, Domain seam (see include/zkt_plonk.h).
 #include "ctx.hpp"
 #include "hostinv.hpp"
+#include "ec.hpp"
 
 #include <cstring>
 
@@ -290,7 +291,33 @@ static void host_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t
     memcpy(out, r.v, P::N * 4);
 }
 
+template <class C>
+static void g1_sum_host(const uint64_t* pts, size_t count, uint64_t* out, int* out_inf) {
+    using Q = typename C::Fq;
+    constexpr int L = Q::N / 2;   // u64 limbs per coordinate
+    Xyzz<Q> acc = xyzz_identity<Q>();
+    for (size_t i = 0; i < count; ++i) {
+        Affine<Q> a;
+        memcpy(a.x.v, pts + i * 2 * L, Q::N * 4);
+        memcpy(a.y.v, pts + i * 2 * L + L, Q::N * 4);
+        if (aff_is_inf<Q>(a)) continue;
+        acc = xyzz_add_mixed<Q>(acc, a);
+    }
+    const Affine<Q> r = xyzz_to_affine_host<Q>(acc);
+    memcpy(out, r.x.v, Q::N * 4);
+    memcpy(out + L, r.y.v, Q::N * 4);
+    if (out_inf) *out_inf = aff_is_inf<Q>(r) ? 1 : 0;
+}
+
 extern "C" {
+
+int zkt_g1_sum_host(int curve_id, const uint64_t* pts, size_t count, uint64_t* out, int* out_inf) {
+    if ((!pts && count) || !out) return ZKT_ERR_INVALID_ARGUMENT;
+    if (curve_id == ZKT_CURVE_BN254) g1_sum_host<Bn254Curve>(pts, count, out, out_inf);
+    else if (curve_id == ZKT_CURVE_BLS12_381) g1_sum_host<Bls381Curve>(pts, count, out, out_inf);
+    else return ZKT_ERR_INVALID_ARGUMENT;
+    return ZKT_OK;
+}
 
 int zkt_host_field_op(int curve_id, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     if (!a || !b || !out) return ZKT_ERR_INVALID_ARGUMENT;

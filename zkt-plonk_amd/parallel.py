@@ -1,7 +1,8 @@
-"""Multi-GPU layer: one process per GPU, independent proofs sharded across ranks (SURVEY.md section 8e,
-"the MSMs of one proof / of concurrent proofs are independent units").  There is no data-path collective:
-torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only for the barrier and for the
-max-over-ranks timing that bench.py reports."""
+"""Multi-GPU layer: one process per GPU.  Independent proofs are sharded across ranks ("the
+MSMs of one proof / of concurrent proofs are independent units"): no data-path collective, torch.distributed (RCCL on
+GPUs, gloo in the CPU tests) only carries the barrier and the max-over-ranks timing that bench.py reports.
+`sharded_msm_combine` is the one exchange step of an MSM whose points are split by index range: an all-gather of the
+partial sums as raw bytes and a local addition (a collective cannot reduce curve points)."""
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple
@@ -55,3 +56,20 @@ def gather_proofs(dist, proofs: Sequence[bytes], device=None) -> List[bytes]:
         for k in range(int(counts[r].item())):
             out.append(raw[k * size:(k + 1) * size])
     return out
+
+
+def sharded_msm_combine(dist, curve, partial_xy, partial_is_inf: bool, device=None):
+    """All-gather every rank's partial MSM result (affine, Montgomery limbs; identity = (0, 0)) and add them on the
+    host: every rank returns the full sum -> (xy limbs, is_infinity).  SURVEY.md section 8e: rank g holds the SRS slice
+    [g n/G, (g+1) n/G) and computes sum_i s_i P_i over it; 64-96 bytes per rank cross xGMI."""
+    import numpy as np
+    from ._lib import g1_sum_host
+    mine = np.zeros_like(np.asarray(partial_xy, dtype=np.uint64)) if partial_is_inf else np.asarray(partial_xy, dtype=np.uint64)
+    if dist is None or not dist.is_initialized():
+        return g1_sum_host(curve, mine.reshape(1, -1))
+    import torch
+    t = torch.from_numpy(mine.view(np.int64).copy()).to(device) if device is not None else torch.from_numpy(mine.view(np.int64).copy())
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    pts = np.stack([p.cpu().numpy().view(np.uint64) for p in parts])
+    return g1_sum_host(curve, pts)
