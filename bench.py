@@ -125,8 +125,8 @@ def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--curve", default="bn254", choices=sorted(FIELDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
