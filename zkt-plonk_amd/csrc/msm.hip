@@ -9,9 +9,9 @@
 //    2^(c*w) * P_i precomputed in affine form ([w][i] table in HBM).  All windows then share ONE set
 //    of 2^(c-1) buckets: there is no per-window bucket reduction and no Horner pass over windows.
 //  * Signed c-bit digits halve the bucket count; a negative digit negates y on the fly.
-//  * (bucket, table index) pairs are radix-sorted by bucket; accumulation walks the sorted array in
-//    fixed-size chunks (perfect lane balance whatever the digit distribution), emitting one partial
-//    XYZZ sum per (chunk, bucket) piece at slot chunk + bucket; a second kernel folds a bucket's pieces.
+//  * (bucket, table index) pairs are grouped by bucket with a two-level counting sort (below); accumulation walks
+//    the grouped indices in fixed-size chunks (perfect lane balance whatever the digit distribution), emitting one
+//    partial XYZZ sum per (chunk, bucket) piece at slot chunk + bucket; a second kernel folds a bucket's pieces.
 //  * sum_b b * B_b is computed with short per-thread running sums (segments of 8 buckets), masked
 //    wave/block tree reductions for the segment weights and a final doubling step.
 //  * The single resulting point is normalised (one inversion) on the host, which needs the affine
@@ -26,8 +26,9 @@ namespace zkt {
 
 constexpr int MSM_CHUNK_MIN = 16;  // sorted entries per accumulation thread: at least this many; the actual
                                    // chunk is sized so that ONE resident wave-front of threads covers the array
-constexpr int MSM_SEG = 8;      // buckets per running-sum segment
-constexpr int MSM_R2_BLOCKS = 4;
+constexpr int MSM_LOG_SEG = 2;
+constexpr int MSM_SEG = 1 << MSM_LOG_SEG;   // buckets per running-sum segment
+constexpr int MSM_R2_BLOCKS = 8;
 constexpr int MSM_MAX_Y = 24;
 
 // Window layout: W windows of width c or c-1 covering exactly lambda+1 bits, so that no window
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(64) void k_msm_final(const Xyzz<typename C::Fq>* pa
     int e = 0;
     if (y < ny) {
         for (int j = 0; j < nblk; ++j) v = xx_add<Q>(v, xx_load<Q>(partials + (size_t)y * nblk + j));
-        e = (y == 0) ? 0 : (y - 1) + 3;  // SEG = 8 = 2^3
+        e = (y == 0) ? 0 : (y - 1) + MSM_LOG_SEG;
     } else if (y == ny) {
         v = xx_load<Q>(top_bucket);
         e = c - 1;
@@ -891,7 +892,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, st.side,
                        (const Xyzz<Q>*)st.buckets[slot], nseg, (Xyzz<Q>*)st.segA[slot], (Xyzz<Q>*)st.segT[slot]);
     ZKT_HIP(c, hipGetLastError());
-    int seg_bits = st.c - 1 - 3;  // log2(nseg)
+    int seg_bits = st.c - 1 - MSM_LOG_SEG;  // log2(nseg)
     int ny = 1 + seg_bits;
     hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny), dim3(256), 0, st.side,
                        (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], nseg, (Xyzz<Q>*)st.partials[slot]);
