@@ -57,6 +57,7 @@ struct MsmState {
     uint32_t* bin_aux = nullptr;                   // tile totals, scanned; last = number of pairs
     uint32_t *bin_start = nullptr, *tile_start = nullptr;   // nb1 + 1 each: level-2 work list
     uint32_t *cnt2 = nullptr, *pos2 = nullptr;     // [level-2 tiles][256]
+    uint32_t* chunk_bucket = nullptr;              // bucket of the first pair of every accumulation chunk
     uint32_t nb1 = 0;                              // level-1 bins
     uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
     uint32_t l2_items = 0;                         // upper bound of level-2 tiles
@@ -376,7 +377,8 @@ __global__ __launch_bounds__(256) void k_msm_l2_count(const uint2* pairs, uint32
 
 // one workgroup per bin: positions of every (tile, bucket) run and offsets[bucket]
 __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint32_t* pos2, const uint32_t* bin_start,
-                                                     const uint32_t* tile_start, uint32_t* offsets) {
+                                                     const uint32_t* tile_start, uint32_t* offsets, uint32_t B,
+                                                     uint32_t chunk, uint32_t* chunk_bucket) {
     __shared__ uint32_t tot[256];
     const uint32_t b = blockIdx.x;
     const uint32_t t0 = tile_start[b], t1 = tile_start[b + 1];
@@ -395,7 +397,27 @@ __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint3
         __syncthreads();
     }
     const uint32_t first = bin_start[b] + tot[threadIdx.x] - run;
-    offsets[b * 256u + threadIdx.x] = first;   // sized nb1 * 256 + 2; keys above B are empty and repeat the end
+    const uint32_t key = b * 256u + threadIdx.x;
+    offsets[key] = first;   // sized nb1 * 256 + 2; keys above B are empty and repeat the end
+    // accumulation chunk t starts at pair t * chunk: tell it which bucket that pair belongs to.  A bucket normally
+    // covers a handful of chunks; a crowded one (skewed digits) is written by the whole workgroup.
+    __shared__ uint32_t big[256][3];
+    __shared__ uint32_t nbig;
+    if (threadIdx.x == 0) nbig = 0;
+    __syncthreads();
+    if (key >= 1 && key <= B && run) {
+        const uint32_t tb = (first + chunk - 1) / chunk;
+        const uint32_t te = (uint32_t)(((uint64_t)first + run + chunk - 1) / chunk);   // one past the last chunk start inside
+        if (te - tb > 64) {
+            const uint32_t at = atomicAdd(&nbig, 1u);
+            big[at][0] = key; big[at][1] = tb; big[at][2] = te;
+        } else {
+            for (uint32_t t = tb; t < te; ++t) chunk_bucket[t] = key;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = 0; e < nbig; ++e)
+        for (uint32_t t = big[e][1] + threadIdx.x; t < big[e][2]; t += 256) chunk_bucket[t] = big[e][0];
     for (uint32_t t = t0; t < t1; ++t) pos2[(size_t)t * 256 + threadIdx.x] += first;
 }
 
@@ -441,7 +463,7 @@ __global__ __launch_bounds__(256) void k_msm_l2_scatter(const uint2* pairs, uint
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, uint32_t chunk,
-                                                        const uint32_t* offsets,
+                                                        const uint32_t* offsets, const uint32_t* chunk_bucket,
                                                         const Affine<typename C::Fq>* table,
                                                         XyzzRaw<typename C::Fq>* pieces) {
     using Q = typename C::Fq;
@@ -450,16 +472,7 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
     const uint64_t p0 = (uint64_t)base + (uint64_t)t * chunk;
     if (p0 >= m) return;
     const uint32_t p1 = (uint32_t)((p0 + chunk < m) ? p0 + chunk : m);
-    // bucket of the first pair: the first b with offsets[b + 1] > p0
-    uint32_t cur;
-    {
-        uint32_t lo = 1, hi = B;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (offsets[mid + 1] <= (uint32_t)p0) lo = mid + 1; else hi = mid;
-        }
-        cur = lo;
-    }
+    uint32_t cur = chunk_bucket[t];   // bucket of the first pair (k_msm_l2_scan): offsets[cur] <= p0 < offsets[cur + 1]
     // end of the current bucket and of the next one: the second is fetched a whole bucket ahead, so that moving on
     // to the next bucket does not wait for memory (only runs of empty buckets do)
     uint32_t end = offsets[cur + 1];
@@ -719,6 +732,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
     size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
     if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
     size_t nseg = st->B / MSM_SEG;
     {
         int blocks_per_cu = 0, cus = 0;
@@ -764,7 +778,7 @@ static void msm_release(zkt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
     void* ptrs[] = {st.heavy,   st.table,     st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
-                    st.tile_start, st.cnt2,   st.pos2,  st.offsets, st.pieces};
+                    st.tile_start, st.cnt2,   st.pos2,  st.offsets, st.pieces, st.chunk_bucket};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
@@ -862,7 +876,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         hipLaunchKernelGGL(k_msm_l2_count, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
                            st.bin_start, st.tile_start, st.cnt2);
         hipLaunchKernelGGL(k_msm_l2_scan, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
-                           st.tile_start, st.offsets);
+                           st.tile_start, st.offsets, st.B, chunk, st.chunk_bucket);
         hipLaunchKernelGGL(k_msm_l2_scatter, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
                            st.bin_start, st.tile_start, st.cnt2, st.pos2, st.vals2);
         ZKT_HIP(c, hipGetLastError());
@@ -871,7 +885,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + chunk - 1) / chunk;
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.vals2,
-                           st.B, chunk, st.offsets, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces);
+                           st.B, chunk, st.offsets, st.chunk_bucket, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces);
         ZKT_HIP(c, hipGetLastError());
     }
     // the slot's tail buffers may still be read by the previous MSM that used this slot
