@@ -76,25 +76,38 @@ __global__ void k_lincomb(LinCombArgs a, Fe<P>* out, size_t n) {
 // ---------------------------------------------------------------------------------------------
 constexpr int EV_E = 8;
 constexpr int EV_SEG = 256 * EV_E;
+constexpr int EV_PW = 257;   // x^0 .. x^255 and x^256 per polynomial
 
+// pw[k][t] = point[k]^t, t = 0..256
 template <class P>
-__global__ __launch_bounds__(256) void k_eval_partial(EvalArgs a, Fe<P>* partials, int nblk) {
+__global__ void k_eval_powers(EvalArgs a, Fe<P>* pw) {
+    const int k = blockIdx.x, t = threadIdx.x;
+    if (t < EV_PW) fe_store<P>(pw + (size_t)k * EV_PW + t, fe_pow_u64<P>(arg_fe<P>(a.point[k]), (uint64_t)t));
+}
+
+// One workgroup per 2048 consecutive coefficients: thread t takes c[base + 256 j + t], j = 0..7 (coalesced), runs
+// Horner in x^256 over j, multiplies by x^t, and the workgroup's sum is multiplied by x^base: one product per
+// coefficient.
+template <class P>
+__global__ __launch_bounds__(256) void k_eval_partial(EvalArgs a, const Fe<P>* pw, Fe<P>* partials, int nblk) {
     __shared__ Fe<P> red[256];
     const int k = blockIdx.y;
     const Fe<P>* poly = (const Fe<P>*)a.poly[k];
     const uint64_t len = a.len[k];
-    const Fe<P> x = arg_fe<P>(a.point[k]);
     const uint64_t base = (uint64_t)blockIdx.x * EV_SEG;
     const int t = threadIdx.x;
     Fe<P> acc = fe_zero<P>();
-    const uint64_t i0 = base + (uint64_t)t * EV_E;
-    if (i0 < len) {
-#pragma unroll 1
-        for (int j = EV_E - 1; j >= 0; --j) {
-            acc = fe_mul<P>(acc, x);
-            if (i0 + j < len) acc = fe_add<P>(acc, fe_load<P>(poly + i0 + j));
+    if (base + t < len) {
+        const Fe<P> x256 = fe_load<P>(pw + (size_t)k * EV_PW + 256);
+        Fe<P> c[EV_E];
+#pragma unroll
+        for (int j = 0; j < EV_E; ++j) {
+            const uint64_t i = base + (uint64_t)j * 256 + t;
+            c[j] = (i < len) ? fe_load<P>(poly + i) : fe_zero<P>();
         }
-        acc = fe_mul<P>(acc, fe_pow_u64<P>(x, (uint64_t)t * EV_E));
+#pragma unroll 1
+        for (int j = EV_E - 1; j >= 0; --j) acc = fe_add<P>(fe_mul<P>(acc, x256), c[j]);
+        acc = fe_mul<P>(acc, fe_load<P>(pw + (size_t)k * EV_PW + t));
     }
     red[t] = acc;
     __syncthreads();
@@ -102,7 +115,10 @@ __global__ __launch_bounds__(256) void k_eval_partial(EvalArgs a, Fe<P>* partial
         if (t < d) red[t] = fe_add<P>(red[t], red[t + d]);
         __syncthreads();
     }
-    if (t == 0) fe_store<P>(partials + (size_t)k * nblk + blockIdx.x, fe_mul<P>(red[0], fe_pow_u64<P>(x, base)));
+    if (t == 0 && base < len)
+        fe_store<P>(partials + (size_t)k * nblk + blockIdx.x, fe_mul<P>(red[0], fe_pow_u64<P>(arg_fe<P>(a.point[k]), base)));
+    else if (t == 0)
+        fe_store<P>(partials + (size_t)k * nblk + blockIdx.x, fe_zero<P>());
 }
 
 template <class P>
@@ -671,17 +687,21 @@ template <class P> static int lincomb_t(zkt_ctx* c, const LinCombArgs& a, void* 
 }
 int poly_lincomb(zkt_ctx* c, const LinCombArgs& a, void* out, size_t n) { ZKT_DISPATCH(c, lincomb_t, a, out, n); }
 
-template <class P> static int eval_many_t(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results) {
+template <class P> static int eval_many_t(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results, void* d_powers) {
     uint64_t maxlen = 1;
     for (int k = 0; k < a.count; ++k) if (a.len[k] > maxlen) maxlen = a.len[k];
     int nblk = (int)((maxlen + EV_SEG - 1) / EV_SEG);
-    hipLaunchKernelGGL(k_eval_partial<P>, dim3(nblk, a.count), dim3(256), 0, c->stream, a, (Fe<P>*)d_partials, nblk);
+    hipLaunchKernelGGL(k_eval_powers<P>, dim3(a.count), dim3(320), 0, c->stream, a, (Fe<P>*)d_powers);
+    hipLaunchKernelGGL(k_eval_partial<P>, dim3(nblk, a.count), dim3(256), 0, c->stream, a, (const Fe<P>*)d_powers,
+                       (Fe<P>*)d_partials, nblk);
     ZKT_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(k_eval_final<P>, dim3(a.count), dim3(256), 0, c->stream, (const Fe<P>*)d_partials, nblk, (Fe<P>*)d_results);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
-int poly_eval_many(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results) { ZKT_DISPATCH(c, eval_many_t, a, d_partials, d_results); }
+int poly_eval_many(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results, void* d_powers) {
+    ZKT_DISPATCH(c, eval_many_t, a, d_partials, d_results, d_powers);
+}
 
 template <class P> static int z1_terms_t(zkt_ctx* c, const ZTermsArgs& a) {
     hipLaunchKernelGGL(k_z1_terms<P>, dim3(nblocks(a.n)), dim3(256), 0, c->stream, a);

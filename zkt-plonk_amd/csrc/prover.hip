@@ -54,6 +54,7 @@ struct CircuitState {
     void* pinned = nullptr;
     void* pinned_pi = nullptr;      // host staging of pi_tab
     uint32_t* pi_tab = nullptr;     // device: QUOTIENT_PI_DIRECT_MAX entries of {rotation, 9 limbs}
+    void* eval_pw = nullptr;        // EVAL_MAX x 257 powers of the evaluation points (round 5)
     // The table polynomial depends on the lookup table only: while consecutive proofs pass the same table its
     // evaluations, coefficients, 4n-coset and commitment are reused (one MSM and two transforms less).
     std::vector<uint64_t> cached_table;
@@ -501,7 +502,7 @@ struct Prover {
         }
         void* d_partials = (char*)S.small + 64 * 32;
         void* d_results = (char*)S.small + 32 * 32;
-        if ((rc = poly_eval_many(c, ea, d_partials, d_results))) return rc;
+        if ((rc = poly_eval_many(c, ea, d_partials, d_results, S.eval_pw))) return rc;
         ZKT_HIP(c, hipMemcpyAsync(pin, d_results, 12 * 32, hipMemcpyDeviceToHost, c->stream));
         mark("enqueue evaluations");
         if ((rc = check_status())) return rc;   // synchronises the stream
@@ -643,7 +644,7 @@ static void circuit_release(zkt_ctx* c) {
     fr(S.scan_tmp);
     for (void* p : S.poly) fr(p);
     for (void* p : S.wcos) fr(p);
-    fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab);
+    fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
     if (S.pinned) (void)hipHostFree(S.pinned);
     if (S.pinned_pi) (void)hipHostFree(S.pinned_pi);
     c->circuit.reset();
@@ -702,6 +703,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
+    if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * 257))) return rc;
 
     // extend_prover_key (keys/mod.rs:78-146) on the device
     const int pk_of_cs[10] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, PK_QLOOKUP, PK_QTABLE, PK_S1, PK_S2, PK_S3};
