@@ -416,33 +416,33 @@ __global__ void k_quot_blind(Fe<P>* lo, Fe<P>* mid, Fe<P>* hi, const uint32_t* l
 // opening witness
 // ---------------------------------------------------------------------------------------------
 constexpr int PW_E = 8;
-// out[i] = in[i] * z^i
+constexpr int PW_SEG = 256 * PW_E;
+// pw[0][t] = z^t, pw[1][t] = zinv^t, t = 0..256 (two rows of EV_PW)
 template <class P>
-__global__ void k_mul_pow(const Fe<P>* in, Fe<P>* out, size_t n, Fe<P> z) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t i0 = t * PW_E;
-    if (i0 >= n) return;
-    Fe<P> pw = fe_pow_u64<P>(z, i0);
-#pragma unroll 1
-    for (int e = 0; e < PW_E && i0 + e < n; ++e) {
-        fe_store<P>(out + i0 + e, fe_mul<P>(fe_load<P>(in + i0 + e), pw));
-        pw = fe_mul<P>(pw, z);
+__global__ void k_pow_tables(Fe<P> z, Fe<P> zinv, Fe<P>* pw) {
+    const int t = threadIdx.x;
+    if (t < EV_PW) {
+        fe_store<P>(pw + t, fe_pow_u64<P>(z, (uint64_t)t));
+        fe_store<P>(pw + EV_PW + t, fe_pow_u64<P>(zinv, (uint64_t)t));
     }
 }
-// out[j] = S[j+1] * zinv^(j+1), j < len-1 ; zero beyond
+// out[i] = in[i] * z^(i + shift) for i < n, zero for n <= i < cap.  One workgroup per 2048 consecutive elements, thread t
+// takes i = base + 256 j + t (coalesced): z^i = z^(base + shift) * z^t * (z^256)^j costs two products per element.
 template <class P>
-__global__ void k_witness_finish(const Fe<P>* S, Fe<P>* out, size_t len, size_t cap, Fe<P> zinv) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t j0 = t * PW_E;
-    if (j0 >= cap) return;
-    Fe<P> pw = fe_pow_u64<P>(zinv, j0 + 1);
+__global__ __launch_bounds__(256) void k_mul_pow(const Fe<P>* in, Fe<P>* out, size_t n, size_t cap, Fe<P> z, const Fe<P>* pw,
+                                                 uint64_t shift) {
+    __shared__ Fe<P> zb;
+    const size_t base = (size_t)blockIdx.x * PW_SEG;
+    if (threadIdx.x == 0) zb = fe_pow_u64<P>(z, (uint64_t)base + shift);
+    __syncthreads();
+    const Fe<P> z256 = fe_load<P>(pw + 256);
+    Fe<P> r = fe_mul<P>(zb, fe_load<P>(pw + threadIdx.x));
 #pragma unroll 1
-    for (int e = 0; e < PW_E && j0 + e < cap; ++e) {
-        size_t j = j0 + e;
-        Fe<P> v = fe_zero<P>();
-        if (j + 1 < len) v = fe_mul<P>(fe_load<P>(S + j + 1), pw);
-        fe_store<P>(out + j, v);
-        pw = fe_mul<P>(pw, zinv);
+    for (int j = 0; j < PW_E; ++j) {
+        const size_t i = base + (size_t)j * 256 + threadIdx.x;
+        if (i >= cap) break;
+        fe_store<P>(out + i, i < n ? fe_mul<P>(fe_load<P>(in + i), r) : fe_zero<P>());
+        r = fe_mul<P>(r, z256);
     }
 }
 
@@ -823,19 +823,26 @@ int quotient_split_blind(zkt_ctx* c, const void* q, size_t n, const void* d_b0b1
     ZKT_DISPATCH(c, quot_split_t, q, n, d_b0b1, q_lo, q_mid, q_hi, d_status);
 }
 
-template <class P> static int open_witness_t(zkt_ctx* c, const void* p, size_t len, const uint32_t* z, const uint32_t* zinv, void* ta, void* tb, void* scan_tmp, void* out) {
+template <class P> static int open_witness_t(zkt_ctx* c, const void* p, size_t len, const uint32_t* z, const uint32_t* zinv, void* ta, void* tb, void* scan_tmp, void* out, void* d_powers) {
     if (len == 0) return ZKT_OK;
-    unsigned blocks = nblocks((len + PW_E - 1) / PW_E);
-    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)p, (Fe<P>*)ta, len, host_fe<P>(z));
+    // w_j = z^-(j+1) * sum_{i > j} p_i z^i: scale by z^i, suffix sums, scale by z^-(j+1)
+    const Fe<P> zz = host_fe<P>(z), zi = host_fe<P>(zinv);
+    Fe<P>* pw = (Fe<P>*)d_powers;
+    const unsigned blocks = (unsigned)((len + PW_SEG - 1) / PW_SEG);
+    hipLaunchKernelGGL(k_pow_tables<P>, dim3(1), dim3(320), 0, c->stream, zz, zi, pw);
+    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)p, (Fe<P>*)ta, len, len, zz,
+                       (const Fe<P>*)pw, (uint64_t)0);
     ZKT_HIP(c, hipGetLastError());
     int rc = scan_t<P, OpAdd>(c, (const Fe<P>*)ta, (Fe<P>*)tb, len, true, (Fe<P>*)scan_tmp);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_witness_finish<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)tb, (Fe<P>*)out, len, len, host_fe<P>(zinv));
+    // out[j] = S[j + 1] * zinv^(j + 1) for j + 1 < len, zero at j = len - 1
+    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)tb + 1, (Fe<P>*)out, len - 1, len, zi,
+                       (const Fe<P>*)pw + EV_PW, (uint64_t)1);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
-int open_witness(zkt_ctx* c, const void* p, size_t len, const uint32_t z[8], const uint32_t z_inv[8], void* d_tmp_a, void* d_tmp_b, void* d_scan_tmp, void* out) {
-    ZKT_DISPATCH(c, open_witness_t, p, len, z, z_inv, d_tmp_a, d_tmp_b, d_scan_tmp, out);
+int open_witness(zkt_ctx* c, const void* p, size_t len, const uint32_t z[8], const uint32_t z_inv[8], void* d_tmp_a, void* d_tmp_b, void* d_scan_tmp, void* out, void* d_powers) {
+    ZKT_DISPATCH(c, open_witness_t, p, len, z, z_inv, d_tmp_a, d_tmp_b, d_scan_tmp, out, d_powers);
 }
 
 template <class P> static int gen_powers_t(zkt_ctx* c, void* out, size_t n, const uint32_t* base, const uint32_t* scale) {

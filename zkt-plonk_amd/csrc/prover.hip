@@ -591,7 +591,7 @@ struct Prover {
             void* comb = S.sc[0];  // n + 8 fits: sc buffers hold n + 8 elements
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv_host<R>(xi);
-            if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
+            if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
             if ((rc = commit_begin(S.sc[3], cap - 1, 0))) return rc;  // the scalars are consumed by the first kernel
         }
         {   // saw opening (prove.rs:427-451): (z1, z2, t, h1) at xi * omega
@@ -605,7 +605,7 @@ struct Prover {
             void* comb = S.sc[0];
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv_host<R>(shifted);
-            if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3]))) return rc;
+            if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
             if ((rc = commit_begin(S.sc[3], cap - 1, 1))) return rc;
             if ((rc = commit_end(0, &aw))) return rc;
             if ((rc = commit_end(1, &saw))) return rc;
