@@ -78,11 +78,14 @@ constexpr int EV_E = 8;
 constexpr int EV_SEG = 256 * EV_E;
 constexpr int EV_PW = 257;   // x^0 .. x^255 and x^256 per polynomial
 
-// pw[k][t] = point[k]^t, t = 0..256
+// pw[k][t] = point[k]^t for t = 0..256, followed by pw[k][257 + b] = point[k]^(2048 b) for b < nblk
 template <class P>
-__global__ void k_eval_powers(EvalArgs a, Fe<P>* pw) {
-    const int k = blockIdx.x, t = threadIdx.x;
-    if (t < EV_PW) fe_store<P>(pw + (size_t)k * EV_PW + t, fe_pow_u64<P>(arg_fe<P>(a.point[k]), (uint64_t)t));
+__global__ void k_eval_powers(EvalArgs a, Fe<P>* pw, int nblk) {
+    const int k = blockIdx.x;
+    const Fe<P> x = arg_fe<P>(a.point[k]);
+    Fe<P>* row = pw + (size_t)k * (EV_PW + nblk);
+    for (int t = threadIdx.x; t < EV_PW + nblk; t += blockDim.x)
+        fe_store<P>(row + t, fe_pow_u64<P>(x, t < EV_PW ? (uint64_t)t : (uint64_t)(t - EV_PW) * EV_SEG));
 }
 
 // One workgroup per 2048 consecutive coefficients: thread t takes c[base + 256 j + t], j = 0..7 (coalesced), runs
@@ -93,12 +96,13 @@ __global__ __launch_bounds__(256) void k_eval_partial(EvalArgs a, const Fe<P>* p
     __shared__ Fe<P> red[256];
     const int k = blockIdx.y;
     const Fe<P>* poly = (const Fe<P>*)a.poly[k];
+    const Fe<P>* row = pw + (size_t)k * (EV_PW + nblk);
     const uint64_t len = a.len[k];
     const uint64_t base = (uint64_t)blockIdx.x * EV_SEG;
     const int t = threadIdx.x;
     Fe<P> acc = fe_zero<P>();
     if (base + t < len) {
-        const Fe<P> x256 = fe_load<P>(pw + (size_t)k * EV_PW + 256);
+        const Fe<P> x256 = fe_load<P>(row + 256);
         Fe<P> c[EV_E];
 #pragma unroll
         for (int j = 0; j < EV_E; ++j) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void k_eval_partial(EvalArgs a, const Fe<P>* p
         }
 #pragma unroll 1
         for (int j = EV_E - 1; j >= 0; --j) acc = fe_add<P>(fe_mul<P>(acc, x256), c[j]);
-        acc = fe_mul<P>(acc, fe_load<P>(pw + (size_t)k * EV_PW + t));
+        acc = fe_mul<P>(acc, fe_load<P>(row + t));
     }
     red[t] = acc;
     __syncthreads();
@@ -115,10 +119,9 @@ __global__ __launch_bounds__(256) void k_eval_partial(EvalArgs a, const Fe<P>* p
         if (t < d) red[t] = fe_add<P>(red[t], red[t + d]);
         __syncthreads();
     }
-    if (t == 0 && base < len)
-        fe_store<P>(partials + (size_t)k * nblk + blockIdx.x, fe_mul<P>(red[0], fe_pow_u64<P>(arg_fe<P>(a.point[k]), base)));
-    else if (t == 0)
-        fe_store<P>(partials + (size_t)k * nblk + blockIdx.x, fe_zero<P>());
+    if (t == 0)
+        fe_store<P>(partials + (size_t)k * nblk + blockIdx.x,
+                    base < len ? fe_mul<P>(red[0], fe_load<P>(row + EV_PW + blockIdx.x)) : fe_zero<P>());
 }
 
 template <class P>
@@ -691,7 +694,7 @@ template <class P> static int eval_many_t(zkt_ctx* c, const EvalArgs& a, void* d
     uint64_t maxlen = 1;
     for (int k = 0; k < a.count; ++k) if (a.len[k] > maxlen) maxlen = a.len[k];
     int nblk = (int)((maxlen + EV_SEG - 1) / EV_SEG);
-    hipLaunchKernelGGL(k_eval_powers<P>, dim3(a.count), dim3(320), 0, c->stream, a, (Fe<P>*)d_powers);
+    hipLaunchKernelGGL(k_eval_powers<P>, dim3(a.count), dim3(1024), 0, c->stream, a, (Fe<P>*)d_powers, nblk);
     hipLaunchKernelGGL(k_eval_partial<P>, dim3(nblk, a.count), dim3(256), 0, c->stream, a, (const Fe<P>*)d_powers,
                        (Fe<P>*)d_partials, nblk);
     ZKT_HIP(c, hipGetLastError());

@@ -703,7 +703,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
-    if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * 257))) return rc;
+    if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * (257 + eval_blocks)))) return rc;
 
     // extend_prover_key (keys/mod.rs:78-146) on the device
     const int pk_of_cs[10] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, PK_QLOOKUP, PK_QTABLE, PK_S1, PK_S2, PK_S3};
