@@ -255,9 +255,15 @@ __global__ __launch_bounds__(1024) void k_msm_scan_tiles(uint32_t* counts, uint3
     }
     if (threadIdx.x == 0) aux[blockIdx.x] = all;
 }
-// aux[0 .. nt) -> exclusive, aux[nt] = grand total.  One workgroup.  Also resets the crowded-bucket counter of this
-// MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
-__global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t nt, uint32_t* heavy_count) {
+ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, size_t total) {
+    return (i < total) ? offs[i] + aux[i / MSM_SCAN_TILE] : aux[(total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE];
+}
+// One workgroup: aux[0 .. nt) -> exclusive, aux[nt] = grand total; then the level-2 work list (bin b owns tiles
+// [tile_start[b], tile_start[b + 1]) of MSM_L2_TILE pairs each, bin_start[b] = first pair of bin b); also resets the
+// crowded-bucket counter of this MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
+__global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uint32_t* aux, uint32_t nt, uint32_t nblk,
+                                                       uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start,
+                                                       uint32_t* heavy_count) {
     __shared__ uint32_t wsum[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nt; base += 1024) {
@@ -272,9 +278,20 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(uint32_t* aux, uint32_t n
         aux[nt] = carry;
         *heavy_count = 0;
     }
-}
-ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, size_t total) {
-    return (i < total) ? offs[i] + aux[i / MSM_SCAN_TILE] : aux[(total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE];
+    __syncthreads();   // aux is complete and visible to this workgroup
+    const size_t total = (size_t)nb1 * nblk;
+    uint32_t s = 0, tiles = 0;
+    if (threadIdx.x <= nb1) s = msm_bin_off(offs, aux, (size_t)threadIdx.x * nblk, total);
+    if (threadIdx.x < nb1) {
+        const uint32_t e = msm_bin_off(offs, aux, (size_t)(threadIdx.x + 1) * nblk, total);
+        tiles = (e - s + MSM_L2_TILE - 1) / MSM_L2_TILE;
+    }
+    uint32_t all;
+    const uint32_t ex = block_excl_scan_1024(tiles, wsum, &all);
+    if (threadIdx.x <= nb1) {
+        bin_start[threadIdx.x] = s;
+        tile_start[threadIdx.x] = ex;   // thread nb1 contributes 0 tiles, so this is the grand total there
+    }
 }
 
 // LDS: cursor[nb1] | delta[nb1] | stage uint2[MSM_L1_CAP]
@@ -319,25 +336,6 @@ __global__ __launch_bounds__(1024) void k_msm_bin_scatter(const Fe<typename C::F
     for (uint32_t j = threadIdx.x; j < staged; j += 1024) {
         const uint2 kv = stage[j];
         pairs[delta[kv.x >> MSM_BIN_LB] + j] = kv;
-    }
-}
-
-// level-2 work list: bin b owns tiles [tile_start[b], tile_start[b + 1]) of MSM_L2_TILE pairs each
-__global__ __launch_bounds__(1024) void k_msm_l2_plan(const uint32_t* offs, const uint32_t* aux, uint32_t nblk,
-                                                      uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start) {
-    __shared__ uint32_t wsum[16];
-    const size_t total = (size_t)nb1 * nblk;
-    uint32_t s = 0, tiles = 0;
-    if (threadIdx.x <= nb1) s = msm_bin_off(offs, aux, (size_t)threadIdx.x * nblk, total);
-    if (threadIdx.x < nb1) {
-        const uint32_t e = msm_bin_off(offs, aux, (size_t)(threadIdx.x + 1) * nblk, total);
-        tiles = (e - s + MSM_L2_TILE - 1) / MSM_L2_TILE;
-    }
-    uint32_t all;
-    const uint32_t ex = block_excl_scan_1024(tiles, wsum, &all);
-    if (threadIdx.x <= nb1) {
-        bin_start[threadIdx.x] = s;
-        tile_start[threadIdx.x] = ex;   // thread nb1 contributes 0 tiles, so this is the grand total there
     }
 }
 
@@ -864,13 +862,12 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         hipLaunchKernelGGL(k_msm_bin_count<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream,
                            (const Fe<R>*)d_scalars, n, mont, st.win, S, st.nb1, st.bin_offs);
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
-        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_aux, ntiles, st.heavy);
+        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
+                           st.bin_start, st.tile_start, st.heavy);
         ZKT_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 8 + (size_t)MSM_L1_CAP * 8,
                            c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S, st.count, base_off, st.nb1,
                            st.bin_offs, st.bin_aux, (uint2*)st.pairs);
-        hipLaunchKernelGGL(k_msm_l2_plan, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, nblk, st.nb1,
-                           st.bin_start, st.tile_start);
         ZKT_HIP(c, hipGetLastError());
         const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
         hipLaunchKernelGGL(k_msm_l2_count, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
