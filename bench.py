@@ -205,7 +205,7 @@ def main():
     for _ in range(args.warmup):
         proof = one_proof()
     barrier()
-    ctx.profile_enable(True)
+    ctx.profile_enable(os.environ.get("ZKT_BENCH_NO_EVENTS") is None)
     t_start = time.perf_counter()
     for _ in range(args.steps):
         proof = one_proof()
@@ -213,7 +213,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     barrier()
     prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "msm_main", "msm_tail", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2),
-                                            "ntt_pass", "quotient")}
+                                            "quotient")}
     ctx.profile_enable(False)
     red_dev = dev if (dist is None or dist.get_backend() == "nccl") else None
     elapsed = par.max_over_ranks(dist, elapsed, red_dev)   # whole-job time = slowest rank

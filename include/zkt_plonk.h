@@ -61,8 +61,10 @@ const char* zkt_last_error(const zkt_ctx* ctx);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) for every launch of this context. */
 int zkt_ctx_set_stream(zkt_ctx* ctx, void* hip_stream);
 int zkt_ctx_synchronize(zkt_ctx* ctx);
-/* Per-kernel timing with HIP events on the context's stream (the stream the kernels run on).
- * Names: "ntt_<log2 size>" (whole transform), "ntt_pass", "msm", "msm_accumulate", "quotient". */
+/* Timing with HIP events on the stream the kernels run on (each event pair costs a few microseconds of stream time,
+ * so only these scopes exist).  Names: "ntt_<log2 size>" (whole transform), "msm_main" (grouping, accumulation and
+ * bucket fold of one MSM), "msm_accumulate" (the accumulation kernel alone), "msm_tail" (bucket reduction, on the side
+ * stream), "quotient". */
 int zkt_profile_enable(zkt_ctx* ctx, int on);
 int zkt_profile_get(zkt_ctx* ctx, const char* name, uint64_t* calls, double* total_ms);
 const char* zkt_version(void);

@@ -855,7 +855,6 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     {
     ProfScope prof_all(c, "msm_main");
     {
-        ProfScope prof_sort(c, "msm_group");
         const uint32_t S = st.l1_scalars;
         const unsigned nblk = (unsigned)((n + S - 1) / S);
         const uint32_t total = st.nb1 * nblk, ntiles = (total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;

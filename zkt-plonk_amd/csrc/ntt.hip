@@ -549,7 +549,6 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
         a.in_len = (i == 0) ? (uint64_t)in_len : N;
         a.log_n = (uint32_t)log_n;
         acc += pl.log_r[i];
-        ProfScope prof_pass(c, "ntt_pass");
         if (!last) {
             a.log_s = (uint32_t)(log_n - acc);
             launch_pass<P, false>(c, pl.log_r[i], blocks, a);
