@@ -24,7 +24,7 @@
 
 namespace zkt {
 
-constexpr int MSM_CHUNK_MIN = 16;  // sorted entries per accumulation thread: at least this many; the actual
+constexpr int MSM_CHUNK_MIN = 16;  // grouped pairs per accumulation thread: at least this many; the actual
                                    // chunk is sized so that ONE resident wave-front of threads covers the array
 constexpr int MSM_LOG_SEG = 2;
 constexpr int MSM_SEG = 1 << MSM_LOG_SEG;   // buckets per running-sum segment
@@ -455,9 +455,9 @@ __global__ __launch_bounds__(256) void k_msm_l2_scatter(const uint2* pairs, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// accumulation: fixed-size chunks over the sorted pairs, one piece per (chunk, bucket).
-// Coordinates live in registers as lazily reduced 29-bit limbs (ecx.hpp); table, pieces and buckets
-// are canonical packed words in R' Montgomery form.
+// accumulation: fixed-size chunks over the grouped table indices, one piece per (chunk, bucket).
+// Coordinates live in registers as lazily reduced 29-bit limbs (ecx.hpp); the table and the buckets are canonical
+// packed words in R' Montgomery form, the pieces are the raw limbs (XyzzRaw).
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, uint32_t chunk,
