@@ -210,6 +210,50 @@ def test_full_size_proof_is_accepted_by_the_verifier(ctxs):
     assert not P.verify(cv, tau, vk, P.proof_deserialize(cv, bytes(bad)), P.new_seeded_transcript(cv, vk), pis)
 
 
+def test_chained_proofs_with_prefetch(ctxs):
+    """zkt_prove_set_next: rounds 1 and 2 of the announced proof are issued behind the current proof's last commitments.
+    The bytes must not change - when the announcement is honoured, when a different proof follows, and when another MSM
+    call gets in between (which invalidates the early work)."""
+    import torch
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 900, 64, seed=77)
+    n = cs.circuit_bound()
+    tau = 0xC4A1
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    ctx.srs_load(srs_arr)
+    z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+    a, b, c = cs.wire_evals(cs.n_gates)
+    dev = torch.device("cuda", 0)
+    wires = [torch.from_numpy(K.fr_to_mont(cv, w).view(np.int64)).to(dev) for w in (a, b, c)]
+    pi_pos = sorted(cs.pi)
+    pi_vals = K.fr_to_mont(cv, [cs.pi[k] for k in pi_pos])
+    table = K.fr_to_mont(cv, cs.table)
+    bl = [field_elems(cv.fr.p, 500 + i, P.NUM_BLINDERS) for i in range(4)]
+    want = [P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), x).serialize(cv) for x in bl]
+    preps = [ctx.prepare_dev(wires[0].data_ptr(), wires[1].data_ptr(), wires[2].data_ptr(), cs.n_gates, table, pi_pos,
+                             pi_vals, K.fr_to_mont(cv, x)) for x in bl]
+
+    def tr():
+        t = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+        return z.seed_transcript(t, vk.n, vk.commits)
+
+    # honoured announcements: 0 -> 1 -> 2
+    assert ctx.prove_prepared(preps[0], tr(), preps[1]) == want[0]
+    assert ctx.prove_prepared(preps[1], tr(), preps[2]) == want[1]
+    # 2 was announced and runs; it announces 3, but 0 follows instead: the early work is redone
+    assert ctx.prove_prepared(preps[2], tr(), preps[3]) == want[2]
+    assert ctx.prove_prepared(preps[0], tr(), preps[1]) == want[0]
+    # an unrelated MSM between the announcement and the proof invalidates the early commitments
+    ctx.msm(K.fr_to_mont(cv, [3, 5, 7]))
+    assert ctx.prove_prepared(preps[1], tr()) == want[1]
+    # and a plain proof afterwards is unaffected
+    assert ctx.prove_prepared(preps[3], tr()) == want[3]
+
+
 def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
     """Second and third proof on the same loaded circuit take the cached-table path (same table), then a
     different table invalidates the cache; every proof must still equal the oracle's bytes."""

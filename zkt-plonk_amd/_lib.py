@@ -101,6 +101,14 @@ class ProveInputs(ctypes.Structure):
                 ("w_o", ctypes.POINTER(ctypes.c_uint32))]
 
 
+class PreparedInputs:
+    """A zkt_prove_inputs struct together with the arrays it points into."""
+
+    def __init__(self, struct, keep):
+        self.struct = struct
+        self._keep = keep
+
+
 def _bind_prover(L):
     vp, u64p_, u8p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint8)
     L.zkt_transcript_new.restype = vp
@@ -124,6 +132,7 @@ def _bind_prover(L):
     L.zkt_circuit_setup.argtypes = [vp, ctypes.c_int, ctypes.POINTER(u64p_), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int,
                                     u64p_, ctypes.POINTER(ctypes.c_int)]
     L.zkt_prove.argtypes = [vp, ctypes.POINTER(ProveInputs), vp, u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.zkt_prove_set_next.argtypes = [vp, ctypes.POINTER(ProveInputs)]
 
 
 def g1_sum_host(curve, points) -> tuple:
@@ -350,8 +359,9 @@ class Context:
         self.check(self._L.zkt_circuit_setup(self._h, log_n, ptrs, lens, 0, u64p(out), inf))
         return out, np.array([bool(x) for x in inf])
 
-    def prove_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
-        """Same as prove() with the three wire vectors already resident in HBM (device pointers)."""
+    def prepare_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders) -> "PreparedInputs":
+        """zkt_prove_inputs for wire vectors already resident in HBM (device pointers), built once and reusable: the
+        prefetch of zkt_prove_set_next recognises the next proof by the identity of these pointers."""
         table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
         pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
         blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
@@ -360,10 +370,21 @@ class Context:
         cast = lambda p: ctypes.cast(ctypes.c_void_p(p), ctypes.POINTER(ctypes.c_uint64))
         inp = ProveInputs(cast(d_a), cast(d_b), cast(d_c), n_rows, u64p(table) if table.size else null, table.shape[0],
                           pos, u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 1)
+        return PreparedInputs(inp, (table, pi_vals, blinders, pos))
+
+    def prove_prepared(self, prep: "PreparedInputs", transcript, next_prep: "PreparedInputs" = None) -> bytes:
+        """zkt_prove on prepared inputs.  next_prep announces the proof that follows (zkt_prove_set_next): its
+        challenge-free rounds 1 and 2 are issued behind this proof's last commitments."""
+        if next_prep is not None:
+            self.check(self._L.zkt_prove_set_next(self._h, ctypes.byref(next_prep.struct)))
         out = (ctypes.c_uint8 * 2048)()
         n = ctypes.c_size_t(0)
-        self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))
+        self.check(self._L.zkt_prove(self._h, ctypes.byref(prep.struct), transcript.handle, out, 2048, ctypes.byref(n)))
         return bytes(out[:n.value])
+
+    def prove_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
+        """Same as prove() with the three wire vectors already resident in HBM (device pointers)."""
+        return self.prove_prepared(self.prepare_dev(d_a, d_b, d_c, n_rows, table, pi_pos, pi_vals, blinders), transcript)
 
     def prove(self, a, b, c, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
         """proof_system::prove (prove.rs:59-470); all arrays are (len, 4) Montgomery uint64."""

@@ -49,6 +49,7 @@ struct zkt_ctx {
     std::vector<hipEvent_t> event_pool;
 
     std::shared_ptr<zkt::MsmState> msm;
+    uint64_t msm_epoch = 0;   // bumped by every MSM enqueue and SRS (re)load: work issued ahead of time is tied to it
     std::shared_ptr<zkt::CircuitState> circuit;
     std::vector<void*> owned;  // every hipMalloc made on behalf of this ctx
 };

@@ -65,7 +65,7 @@ struct MsmState {
     void* pieces = nullptr;       // XyzzRaw[max_chunks + B + 2]
     // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
     // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
-    static constexpr int SLOTS = 6;
+    static constexpr int SLOTS = 8;
     void* buckets[SLOTS] = {};      // Xyzz[B + 1]
     void* segA[SLOTS] = {};         // Xyzz[B / SEG]
     void* segT[SLOTS] = {};
@@ -752,6 +752,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_done[i], hipEventDisableTiming));
     }
     c->msm = st;
+    ++c->msm_epoch;
     return ZKT_OK;
 }
 
@@ -847,6 +848,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     using Q = typename C::Fq;
     using R = typename C::Fr;
     MsmState& st = *c->msm;
+    ++c->msm_epoch;   // slot buffers change hands: anything issued ahead of time that relied on them is stale
     const uint32_t m = (uint32_t)((size_t)st.W * n);
     // one chunk per thread, and exactly as many threads as the chip keeps resident for this kernel: the
     // whole array is consumed in a single wave-front with no partially filled last round

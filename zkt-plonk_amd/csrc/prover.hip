@@ -49,6 +49,12 @@ struct CircuitState {
     uint32_t* status = nullptr;  // [0] error bits, [1] len scratch ... [4..7] quotient lens, [8..] poly lens
     uint32_t* lk_u32 = nullptr;  // lookup: perm, base counts, starts of the even half, of the odd half, hit counts
     uint32_t lk_nkeys = 0;       // keys of the resident lookup tables (0 = none)
+    std::vector<uint32_t> lk_host_keys, lk_host_sorted, lk_host_counts, lk_host_order;   // host staging (8 words per key)
+    // zkt_prove_set_next: rounds 1 and 2 of the NEXT proof depend on no challenge; they are issued behind the last
+    // commitments of the current proof, so the GPU never drains between two proofs
+    bool has_next = false, prefetched = false, prefetch_same_table = false;
+    uint64_t prefetch_epoch = 0;   // zkt_ctx::msm_epoch right after the early work was issued
+    zkt_prove_inputs next_in{}, prefetch_in{};
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
@@ -206,8 +212,6 @@ struct Prover {
     }
 
     // lookup/multiset.rs:103-146 on the device; table = distinct values in insertion order
-    std::vector<F> lk_host_keys, lk_host_sorted;
-    std::vector<uint32_t> lk_host_counts, lk_host_order;
     // `fresh` = the lookup table differs from the previous proof's: its keys (insertion order and sorted), the
     // sort permutation and the base multiplicities are rebuilt and uploaded; otherwise they are still resident.
     int combine_split(const uint64_t* table, size_t table_len, bool fresh) {
@@ -220,12 +224,22 @@ struct Prover {
         uint32_t* d_odd = S.lk_u32 + 3 * S.lk_cap;
         uint32_t* d_hits = S.lk_u32 + 4 * S.lk_cap;   // zero between proofs (k_lookup_starts clears what it reads)
         if (fresh || S.lk_nkeys == 0) {
-            // host staging lives in the prover object (alive until the proof's final synchronisation): the copies
-            // below are asynchronous and nothing here waits
-            std::vector<F>& keys = lk_host_keys;
-            std::vector<F>& sorted = lk_host_sorted;
-            std::vector<uint32_t>& counts = lk_host_counts;
-            std::vector<uint32_t>& order = lk_host_order;
+            // host staging lives in the circuit state (the copies below are asynchronous and nothing here waits)
+            static_assert(sizeof(F) == 32, "scalar field element = 8 words");
+            S.lk_host_keys.resize((table_len + 1) * 8);
+            S.lk_host_sorted.resize((table_len + 1) * 8);
+            std::vector<uint32_t>& counts = S.lk_host_counts;
+            std::vector<uint32_t>& order = S.lk_host_order;
+            struct Span {   // a growable view of F over the word vectors
+                std::vector<uint32_t>& w;
+                size_t len;
+                F& operator[](size_t i) { return *reinterpret_cast<F*>(w.data() + 8 * i); }
+                void resize(size_t k) { len = k; }
+                void push_back(const F& v) { (*this)[len] = v; ++len; }
+                size_t size() const { return len; }
+                F* data() { return reinterpret_cast<F*>(w.data()); }
+            };
+            Span keys{S.lk_host_keys, 0}, sorted{S.lk_host_sorted, 0};
             keys.resize(table_len);
             for (size_t i = 0; i < table_len; ++i) keys[i] = H::from_words(table + 4 * i);
             counts.assign(table_len, 1u);
@@ -274,25 +288,33 @@ struct Prover {
         return ZKT_OK;
     }
 
-    int run(const zkt_prove_inputs& in, std::vector<uint8_t>& proof) {
+    static bool same_inputs(const zkt_prove_inputs& a, const zkt_prove_inputs& b) {
+        return a.a_evals == b.a_evals && a.b_evals == b.b_evals && a.c_evals == b.c_evals && a.n_rows == b.n_rows &&
+               a.table == b.table && a.table_len == b.table_len && a.pi_pos == b.pi_pos && a.pi_vals == b.pi_vals &&
+               a.n_pi == b.n_pi && a.blinders == b.blinders && a.wires_on_device == b.wires_on_device &&
+               a.variables == b.variables && a.n_vars == b.n_vars && a.w_l == b.w_l && a.w_r == b.w_r && a.w_o == b.w_o;
+    }
+    int to_coset(int k) {
+        // quotient_poly.rs:52-96 needs every witness polynomial on the 4n coset.  None of those transforms depends on a
+        // challenge, so each is issued right behind the commitment of its polynomial, where it hides the latency-bound
+        // tail of the last MSM of the round (which runs on the side stream).
+        static const int coset_src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
+        return ntt_run(c, S.log_n + 2, 0, 1, S.poly[coset_src[k]], S.n + 8, S.wcos[k]);
+    }
+
+    // Everything of rounds 1 and 2 that runs on the device (prove.rs:116-185): no challenge is needed before beta, so
+    // this part touches no transcript and can be issued ahead of time (zkt_prove_set_next).  Commitments: slots 0-5.
+    int enqueue_rounds_1_2(const zkt_prove_inputs& in, bool* same_table_out) {
         const size_t n = S.n;
-        const int log_n = S.log_n;
         int rc;
         if (in.n_rows > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "more rows than the circuit bound");
         if (in.table_len >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "max table size is equal or larger than n");
         if (n < 8) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "circuit bound below 8");
+        if (!in.blinders) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null blinders");
         ZKT_HIP(c, hipMemsetAsync(S.status, 0, 64 * 4, c->stream));
         ZKT_HIP(c, hipMemcpyAsync(S.small, in.blinders, 19 * 32, hipMemcpyHostToDevice, c->stream));
 
-        // prove.rs:110 -- public inputs (BTreeMap order = ascending position)
-        {
-            std::vector<uint8_t> b(in.n_pi * 32);
-            for (size_t i = 0; i < in.n_pi; ++i) H::to_le_bytes(H::from_words(in.pi_vals + 4 * i), b.data() + 32 * i);
-            tr.append_scalars("pi", b.data(), in.n_pi, 32, false);
-        }
-
         // ---- round 1 (prove.rs:116-140) ----
-        mark("start");
         const uint64_t* wires[3] = {in.a_evals, in.b_evals, in.c_evals};
         const bool from_vars = in.a_evals == nullptr && in.variables != nullptr;
         const void* d_vars = in.variables;
@@ -326,19 +348,12 @@ struct Prover {
             }
             if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
         }
-        Affine<Q> cm[11];
-        static const char* L1[3] = {"a_commit", "b_commit", "c_commit"};
         for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
-        // quotient_poly.rs:52-96 needs every witness polynomial on the 4n coset.  None of those transforms
-        // depends on a challenge, so each is issued right behind the commitment of its polynomial, where it
-        // hides the latency-bound tail of the last MSM of the round (which runs on the side stream).
-        const int coset_src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
-        auto to_coset = [&](int k) { return ntt_run(c, log_n + 2, 0, 1, S.poly[coset_src[k]], n + 8, S.wcos[k]); };
 
-        // ---- round 2 (prove.rs:145-185): nothing here waits for a challenge either, so its three commitments
-        // join the same batch before the transcript sees a_commit
+        // ---- round 2 (prove.rs:145-185): its three commitments join the same batch
         const bool same_table = S.t_cached && S.cached_table.size() == 4 * in.table_len &&
                                 (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
+        *same_table_out = same_table;
         if (!same_table) {
             S.t_cached = false;
             S.t_coset_valid = false;
@@ -356,6 +371,31 @@ struct Prover {
         for (int k : {W_A, W_B, W_C}) if ((rc = to_coset(k))) return rc;
         if (!S.t_coset_valid && (rc = to_coset(W_T))) return rc;   // unchanged table: its coset is still resident
         for (int k : {W_H1, W_H2}) if ((rc = to_coset(k))) return rc;
+        return ZKT_OK;
+    }
+
+    int run(const zkt_prove_inputs& in, std::vector<uint8_t>& proof) {
+        const size_t n = S.n;
+        const int log_n = S.log_n;
+        int rc;
+        mark("start");
+        bool same_table = false;
+        if (S.prefetched && S.prefetch_epoch == c->msm_epoch && same_inputs(S.prefetch_in, in)) {
+            same_table = S.prefetch_same_table;   // rounds 1 and 2 are already in flight
+            S.prefetched = false;
+        } else {
+            S.prefetched = false;
+            if ((rc = enqueue_rounds_1_2(in, &same_table))) return rc;
+        }
+
+        // prove.rs:110 -- public inputs (BTreeMap order = ascending position)
+        {
+            std::vector<uint8_t> b(in.n_pi * 32);
+            for (size_t i = 0; i < in.n_pi; ++i) H::to_le_bytes(H::from_words(in.pi_vals + 4 * i), b.data() + 32 * i);
+            tr.append_scalars("pi", b.data(), in.n_pi, 32, false);
+        }
+        Affine<Q> cm[11];
+        static const char* L1[3] = {"a_commit", "b_commit", "c_commit"};
         mark("enqueue rounds 1+2");
         for (int k = 0; k < 3; ++k) {
             if ((rc = commit_end(k, &cm[k]))) return rc;
@@ -592,7 +632,7 @@ struct Prover {
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv_host<R>(xi);
             if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
-            if ((rc = commit_begin(S.sc[3], cap - 1, 0))) return rc;  // the scalars are consumed by the first kernel
+            if ((rc = commit_begin(S.sc[3], cap - 1, 6))) return rc;  // the scalars are consumed by the first kernels
         }
         {   // saw opening (prove.rs:427-451): (z1, z2, t, h1) at xi * omega
             LinCombArgs lo{};
@@ -606,9 +646,19 @@ struct Prover {
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv_host<R>(shifted);
             if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
-            if ((rc = commit_begin(S.sc[3], cap - 1, 1))) return rc;
-            if ((rc = commit_end(0, &aw))) return rc;
-            if ((rc = commit_end(1, &saw))) return rc;
+            if ((rc = commit_begin(S.sc[3], cap - 1, 7))) return rc;
+            if (S.has_next) {   // keep the GPU fed across the proof boundary (zkt_prove_set_next)
+                S.has_next = false;
+                bool st = false;
+                if (enqueue_rounds_1_2(S.next_in, &st) == ZKT_OK) {
+                    S.prefetched = true;
+                    S.prefetch_in = S.next_in;
+                    S.prefetch_same_table = st;
+                    S.prefetch_epoch = c->msm_epoch;   // any other MSM before the next proof invalidates it
+                }   // on failure the next zkt_prove redoes the work and reports the error
+            }
+            if ((rc = commit_end(6, &aw))) return rc;
+            if ((rc = commit_end(7, &saw))) return rc;
         }
 
         // ---- Proof (proof.rs:106-155), CanonicalSerialize ----
@@ -910,6 +960,14 @@ int zkt_circuit_setup(zkt_ctx* c, int log_n, const uint64_t* const* evals, const
     if (c->curve == ZKT_CURVE_BN254)
         return circuit_setup_t<Bn254Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
     return circuit_setup_t<Bls381Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
+}
+
+int zkt_prove_set_next(zkt_ctx* c, const zkt_prove_inputs* next) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    c->circuit->has_next = next != nullptr;
+    if (next) c->circuit->next_in = *next;
+    return ZKT_OK;
 }
 
 int zkt_prove(zkt_ctx* c, const zkt_prove_inputs* in, zkt_transcript* tr, uint8_t* proof_out, size_t proof_cap,
