@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libzkt_plonk_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-ffp-contract=off"]
+         "-Wno-unused-variable", "-Wno-psabi", "-ffp-contract=off"]
 
 
 def _sources():
