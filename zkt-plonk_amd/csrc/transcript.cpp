@@ -72,7 +72,7 @@ void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
 
 // ---- STROBE-128 (subset used by merlin) -----------------------------------------------------------
 namespace {
-constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, FLAG_K = 32;
+constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_M = 16, FLAG_K = 32;   // FLAG_T = 8 (transport) is never used by merlin
 }
 
 Strobe128::Strobe128(const std::string& protocol_label) {
