@@ -211,7 +211,8 @@ int zkt_prove(zkt_ctx* ctx, const zkt_prove_inputs* in, zkt_transcript* transcri
               size_t proof_cap, size_t* proof_len);
 /* Optional, for back-to-back proofs on one context: announces the inputs of the proof that will follow the next
  * zkt_prove / zkt_prove_with call.  Rounds 1 and 2 (prove.rs:116-185) need no challenge, so that call issues them for
- * `next` behind its own last commitments, and the GPU does not drain between the two proofs.  The following zkt_prove must
+ * `next` behind its own quotient commitments (round 1) and opening commitments (round 2): their bucket reductions
+ * are latency-bound and leave the GPU nearly empty otherwise, and it no longer drains between the two proofs.  The following zkt_prove must
  * be given the same inputs (same pointers and sizes; the data they point to must stay unchanged meanwhile) - otherwise
  * the early work is simply redone.  NULL withdraws the announcement.  Proof bytes are the same either way. */
 int zkt_prove_set_next(zkt_ctx* ctx, const zkt_prove_inputs* next);

@@ -65,7 +65,7 @@ struct MsmState {
     void* pieces = nullptr;       // XyzzRaw[max_chunks + B + 2]
     // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
     // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
-    static constexpr int SLOTS = 8;
+    static constexpr int SLOTS = 11;
     void* buckets[SLOTS] = {};      // Xyzz[B + 1]
     void* segA[SLOTS] = {};         // Xyzz[B / SEG]
     void* segT[SLOTS] = {};

@@ -52,9 +52,15 @@ struct CircuitState {
     std::vector<uint32_t> lk_host_keys, lk_host_sorted, lk_host_counts, lk_host_order;   // host staging (8 words per key)
     // zkt_prove_set_next: rounds 1 and 2 of the NEXT proof depend on no challenge; they are issued behind the last
     // commitments of the current proof, so the GPU never drains between two proofs
-    bool has_next = false, prefetched = false, prefetch_same_table = false;
+    // Round 1 of the next proof goes behind the quotient commitments of round 4, round 2 behind the opening commitments
+    // of round 5.  Round 1 overwrites what round 5 of the current proof still reads (the wire polynomials) and both
+    // use the status words, so those exist twice; `*_alt` is the set the early work writes.
+    bool has_next = false, prefetch_same_table = false;
+    int prefetch_stage = 0;        // 0 nothing, 1 round 1 issued, 2 rounds 1 and 2 issued (only then it is usable)
     uint64_t prefetch_epoch = 0;   // zkt_ctx::msm_epoch right after the early work was issued
     zkt_prove_inputs next_in{}, prefetch_in{};
+    void* poly_alt[3] = {};
+    uint32_t* status_alt = nullptr;
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
@@ -302,9 +308,14 @@ struct Prover {
         return ntt_run(c, S.log_n + 2, 0, 1, S.poly[coset_src[k]], S.n + 8, S.wcos[k]);
     }
 
+    void swap_work_sets() {   // current <-> alternate copies of what early work of the next proof overwrites
+        for (int k = 0; k < 3; ++k) std::swap(S.poly[k], S.poly_alt[k]);
+        std::swap(S.status, S.status_alt);
+    }
+
     // Everything of rounds 1 and 2 that runs on the device (prove.rs:116-185): no challenge is needed before beta, so
-    // this part touches no transcript and can be issued ahead of time (zkt_prove_set_next).  Commitments: slots 0-5.
-    int enqueue_rounds_1_2(const zkt_prove_inputs& in, bool* same_table_out) {
+    // these two parts touch no transcript and can be issued ahead of time (zkt_prove_set_next).  Commitments: slots 0-5.
+    int enqueue_round_1(const zkt_prove_inputs& in) {
         const size_t n = S.n;
         int rc;
         if (in.n_rows > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "more rows than the circuit bound");
@@ -349,8 +360,14 @@ struct Prover {
             if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
         }
         for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
+        for (int k : {W_A, W_B, W_C}) if ((rc = to_coset(k))) return rc;
+        return ZKT_OK;
+    }
 
-        // ---- round 2 (prove.rs:145-185): its three commitments join the same batch
+    // ---- round 2 (prove.rs:145-185): its three commitments join the batch of round 1
+    int enqueue_round_2(const zkt_prove_inputs& in, bool* same_table_out) {
+        const size_t n = S.n;
+        int rc;
         const bool same_table = S.t_cached && S.cached_table.size() == 4 * in.table_len &&
                                 (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
         *same_table_out = same_table;
@@ -368,7 +385,6 @@ struct Prover {
         if (!same_table && (rc = commit_begin(S.poly[3], n, 3))) return rc;
         if ((rc = commit_begin(S.poly[4], n + 3, 4))) return rc;
         if ((rc = commit_begin(S.poly[5], n + 2, 5))) return rc;
-        for (int k : {W_A, W_B, W_C}) if ((rc = to_coset(k))) return rc;
         if (!S.t_coset_valid && (rc = to_coset(W_T))) return rc;   // unchanged table: its coset is still resident
         for (int k : {W_H1, W_H2}) if ((rc = to_coset(k))) return rc;
         return ZKT_OK;
@@ -380,12 +396,14 @@ struct Prover {
         int rc;
         mark("start");
         bool same_table = false;
-        if (S.prefetched && S.prefetch_epoch == c->msm_epoch && same_inputs(S.prefetch_in, in)) {
-            same_table = S.prefetch_same_table;   // rounds 1 and 2 are already in flight
-            S.prefetched = false;
+        if (S.prefetch_stage == 2 && S.prefetch_epoch == c->msm_epoch && same_inputs(S.prefetch_in, in)) {
+            same_table = S.prefetch_same_table;   // rounds 1 and 2 are already in flight, in the alternate work set
+            swap_work_sets();
+            S.prefetch_stage = 0;
         } else {
-            S.prefetched = false;
-            if ((rc = enqueue_rounds_1_2(in, &same_table))) return rc;
+            S.prefetch_stage = 0;
+            if ((rc = enqueue_round_1(in))) return rc;
+            if ((rc = enqueue_round_2(in, &same_table))) return rc;
         }
 
         // prove.rs:110 -- public inputs (BTreeMap order = ascending position)
@@ -512,8 +530,15 @@ struct Prover {
                 return rc;
             // an unsatisfied circuit shows up as status bits here; they are read with the evaluations of round 5
         }
-        for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[9 + k], n + 3, k))) return rc;
-        for (int k = 0; k < 3; ++k) if ((rc = commit_end(k, &cm[8 + k]))) return rc;
+        for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[9 + k], n + 3, 8 + k))) return rc;
+        if (S.has_next) {   // zkt_prove_set_next: round 1 of the next proof hides the tail of the quotient commitments
+            S.has_next = false;
+            swap_work_sets();
+            const int r1 = enqueue_round_1(S.next_in);
+            swap_work_sets();
+            S.prefetch_stage = (r1 == ZKT_OK) ? 1 : 0;   // on failure the next zkt_prove redoes the work and reports
+        }
+        for (int k = 0; k < 3; ++k) if ((rc = commit_end(8 + k, &cm[8 + k]))) return rc;
         tr_commit("q_lo_commit", cm[8]);
         tr_commit("q_mid_commit", cm[9]);
         tr_commit("q_hi_commit", cm[10]);
@@ -647,15 +672,19 @@ struct Prover {
             F zi = fe_inv_host<R>(shifted);
             if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
             if ((rc = commit_begin(S.sc[3], cap - 1, 7))) return rc;
-            if (S.has_next) {   // keep the GPU fed across the proof boundary (zkt_prove_set_next)
-                S.has_next = false;
+            if (S.prefetch_stage == 1) {   // ... and its round 2 keeps the GPU fed across the proof boundary
                 bool st = false;
-                if (enqueue_rounds_1_2(S.next_in, &st) == ZKT_OK) {
-                    S.prefetched = true;
+                swap_work_sets();
+                const int r2 = enqueue_round_2(S.next_in, &st);
+                swap_work_sets();
+                if (r2 == ZKT_OK) {
+                    S.prefetch_stage = 2;
                     S.prefetch_in = S.next_in;
                     S.prefetch_same_table = st;
                     S.prefetch_epoch = c->msm_epoch;   // any other MSM before the next proof invalidates it
-                }   // on failure the next zkt_prove redoes the work and reports the error
+                } else {
+                    S.prefetch_stage = 0;
+                }
             }
             if ((rc = commit_end(6, &aw))) return rc;
             if ((rc = commit_end(7, &saw))) return rc;
@@ -694,6 +723,8 @@ static void circuit_release(zkt_ctx* c) {
     fr(S.scan_tmp);
     for (void* p : S.poly) fr(p);
     for (void* p : S.wcos) fr(p);
+    for (void* p : S.poly_alt) fr(p);
+    fr(S.status_alt);
     fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
     if (S.pinned) (void)hipHostFree(S.pinned);
     if (S.pinned_pi) (void)hipHostFree(S.pinned_pi);
@@ -747,6 +778,8 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     const size_t eval_blocks = (n + 8 + 2047) / 2048 + 1;
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&S.status_alt, 64 * 4))) return rc;
+    for (auto& p : S.poly_alt) if ((rc = alloc(&p, n + 8))) return rc;
     S.lk_cap = n + 2;
     if ((rc = dev_alloc(c, (void**)&S.lk_u32, 5 * S.lk_cap * 4 + 16))) return rc;
     if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
