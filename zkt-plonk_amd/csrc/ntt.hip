@@ -12,7 +12,7 @@ constexpr int EPT = TILE / NTT_THREADS;
 // LDS tile: every element is held as nine 29-bit limbs (fx.hpp), lazily reduced (< 2p between steps),
 // in three planes (limbs 0-3, 4-7, 8) so that consecutive lanes touch consecutive 16-byte / 4-byte slots.
 template <class P>
-ZKT_D Fx<P> tile_get(const uint4* lo, const uint4* hi, const uint32_t* top, int idx) {
+ZKT_D Fx<P> tile_get(const uint4* lo, const uint4* hi, const uint32_t* top, int64_t idx) {
     static_assert(FxP<P>::L == 9, "scalar fields use nine limbs");
     const uint4 a = lo[idx], b = hi[idx];
     Fx<P> r;
@@ -22,7 +22,7 @@ ZKT_D Fx<P> tile_get(const uint4* lo, const uint4* hi, const uint32_t* top, int 
     return r;
 }
 template <class P>
-ZKT_D void tile_put(uint4* lo, uint4* hi, uint32_t* top, int idx, const Fx<P>& x) {
+ZKT_D void tile_put(uint4* lo, uint4* hi, uint32_t* top, int64_t idx, const Fx<P>& x) {
     lo[idx] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
     hi[idx] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
     top[idx] = x.l[8];
@@ -217,7 +217,13 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
             c = flat >> LOG_R;
         }
         uint64_t g = in_base + (uint64_t)r * ld_r + (uint64_t)c * ld_c;
-        Fx<P> x = (g < a.in_len) ? fx_unpack<P>(fe_load<P>(in + g)) : fx_zero<P>();
+        Fx<P> x;
+        if (a.in_raw) {
+            const uint4* rlo = reinterpret_cast<const uint4*>(a.in);
+            x = tile_get<P>(rlo, rlo + a.raw_n, reinterpret_cast<const uint32_t*>(rlo + 2 * a.raw_n), (int64_t)g);
+        } else {
+            x = (g < a.in_len) ? fx_unpack<P>(fe_load<P>(in + g)) : fx_zero<P>();
+        }
         if (in_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(in_row + r)));
         if (tw) {
             uint64_t ti = LAST ? (tw_base + ((uint64_t)c << LOG_R) + r) : (tw_base + r);
@@ -239,7 +245,13 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
         int rho = (int)bitrev32((uint32_t)k, LOG_R);
         Fx<P> x = tile_get<P>(lds_lo, lds_hi, lds_top, rho * T + c);
         if (out_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(out_row + k)));
-        fe_store<P>(out + out_base + (uint64_t)k * st_k + c, fx_pack<P>(fx_cond_sub_p<P>(x)));
+        const uint64_t at = out_base + (uint64_t)k * st_k + c;
+        if (a.out_raw) {
+            uint4* rlo = reinterpret_cast<uint4*>(a.out);
+            tile_put<P>(rlo, rlo + a.raw_n, reinterpret_cast<uint32_t*>(rlo + 2 * a.raw_n), (int64_t)at, x);
+        } else {
+            fe_store<P>(out + at, fx_pack<P>(fx_cond_sub_p<P>(x)));
+        }
     }
 }
 
@@ -532,7 +544,7 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
         ZKT_HIP(c, hipGetLastError());
         return 0;
     }
-    int rc = ensure_buffer(c, &c->ntt_scratch, &c->ntt_scratch_bytes, N * sizeof(Fe<P>));
+    int rc = ensure_buffer(c, &c->ntt_scratch, &c->ntt_scratch_bytes, N * 36);   // raw limbs between passes
     if (rc) return rc;
     const int p = pl.npass;
     const unsigned blocks = (unsigned)(N >> TILE_LOG);
@@ -548,6 +560,9 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
         a.out_row = last ? pl.out_row : nullptr;
         a.in_len = (i == 0) ? (uint64_t)in_len : N;
         a.log_n = (uint32_t)log_n;
+        a.in_raw = (i == 0) ? 0u : 1u;
+        a.out_raw = last ? 0u : 1u;
+        a.raw_n = N;
         acc += pl.log_r[i];
         if (!last) {
             a.log_s = (uint32_t)(log_n - acc);

@@ -32,6 +32,10 @@ struct NttPassArgs {
     uint32_t log_s;        // non-last: log2 of the inner stride S (columns); last: unused
     uint32_t log_r1;       // last: log2 R1
     uint32_t log_mid;      // last: log2 (N / (R1*Rp))
+    // Between passes the data stay as 29-bit limbs, lazily reduced (< 2p), in three planes of N entries (limbs 0-3,
+    // limbs 4-7, limb 8: the LDS tile's layout, 36 N bytes at raw_base): no packing, reduction or unpacking there.
+    uint32_t in_raw, out_raw;
+    uint64_t raw_n;        // N (plane stride)
 };
 
 template <class P>
