@@ -48,3 +48,22 @@ def test_random_traffic_matches_oracle():
                 else:
                     assert mine.challenge_scalar("beta") == ref.challenge_scalar("beta")
             assert mine.challenge_scalar("eta") == ref.challenge_scalar("eta")
+
+
+def test_seed_in_one_call_equals_the_eleven_appends():
+    """zkt_transcript_seed = VerifierKey::seed_transcript (keys/mod.rs:260-275): circuit_size and the ten commitments."""
+    rnd = random.Random(8)
+    for cv in (F.BN254, F.BLS12_381):
+        kinds = ["merlin"] + (["ethereum"] if cv.name == "bn254" else [])
+        g = (cv.gx, cv.gy)
+        pts = {}
+        for i, name in enumerate(z.PK_ORDER):
+            pts[name] = None if i == 7 else C.scalar_mul(cv, rnd.randrange(1, cv.fr.p), g)   # one identity among them
+        for kind in kinds:
+            a = z.Transcript(kind, "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+            z.seed_transcript(a, 1 << 14, pts)
+            b = z.Transcript(kind, "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+            b.append_u64("circuit_size", 1 << 14)
+            for name in z.PK_ORDER:
+                b.append_commitment(name + "_commit", pts[name])
+            assert a.challenge_scalar("x") == b.challenge_scalar("x")
