@@ -323,10 +323,9 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
     const X beta = arg_fx<P>(q.beta), delta = arg_fx<P>(q.delta), gamma = arg_fx<P>(q.gamma);
     const X a = LD(q.a, i), b = LD(q.b, i), c = LD(q.c, i);
     // keys/arithmetic.rs:67-81 ; q_m is stored as H * 32
-    X acc = fx_mul<P>(fx_mul<P>(a, b), LD(q.q_m, i));
-    acc = fx_add<P>(acc, fx_mul<P>(a, LD(q.q_l, i)));
-    acc = fx_add<P>(acc, fx_mul<P>(b, LD(q.q_r, i)));
-    acc = fx_add<P>(acc, fx_mul<P>(c, LD(q.q_o, i)));
+    // sums of two products share one reduction (fx_mul2_inl) wherever the two terms have the same scaling
+    X acc = fx_mul2_inl<P>(fx_mul<P>(a, b), LD(q.q_m, i), c, LD(q.q_o, i));
+    acc = fx_add<P>(acc, fx_mul2_inl<P>(a, LD(q.q_l, i), b, LD(q.q_r, i)));               // < 4p
     const X l1 = LD(q.l1, i);
     if (q.pi_tab) {   // PI on the coset from rotations of l1 (poly.hpp); two terms per reduction, < 16p in all
         X pi = fx_zero<P>();
@@ -345,9 +344,9 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
             }
             pi = fx_add<P>(pi, fx_mul2_inl<P>(v[0], l[0], v[1], l[1]));
         }
-        acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), pi));                      // < 25p
+        acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), pi));                      // < 21p
     } else {
-        acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), LD(q.pi, i)));             // < 10p
+        acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), LD(q.pi, i)));             // < 6p
     }
     // keys/permutation.rs:97-137
     const X z1 = LD(q.z1, i), z1n = LD(q.z1, j);
@@ -360,13 +359,13 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
         X p1 = fx_mul<P>(z1, ak3);
         p1 = fx_mul<P>(p1, fx_add<P>(bx, ag));
         p1 = fx_mul<P>(p1, fx_add<P>(fx_sub<P, 2>(d8, bx), bg));                 // 2p * 20p
-        p1 = fx_mul<P>(p1, fx_add<P>(fx_add<P>(fx_add<P>(d8, d4), bx), cg));     // 2p * 28p < R'
         X p2 = fx_mul<P>(z1n, ak3);
         p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma1, i), beta), ag));
         p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma2, i), beta), bg));
-        p2 = fx_mul<P>(p2, fx_add<P>(fx_mul<P>(LD(q.sigma3, i), beta), cg));
-        const X p3 = fx_mul<P>(fx_mul<P>(fx_sub<P, 1>(z1, one), l1), arg_fx<P>(q.alpha2));
-        acc = fx_add<P>(acc, fx_add<P>(fx_sub<P, 2>(p1, p2), p3));               // < 31p
+        // p1 * s3 - p2 * t3 with the negated p2 left unnormalised (limbs <= 3 * 2^29): 2p * 28p + 3p * 4p < R' p
+        const X p12 = fx_mul2_inl<P>(p1, fx_add<P>(fx_add<P>(fx_add<P>(d8, d4), bx), cg), fx_sub_lazy<P, 3>(fx_zero<P>(), p2),
+                                     fx_add<P>(fx_mul<P>(LD(q.sigma3, i), beta), cg));
+        acc = fx_add<P>(acc, p12);                                               // < 23p
     }
     {   // keys/lookup.rs:81-122
         const X eps = arg_fx<P>(q.epsilon), eopd = arg_fx<P>(q.eopd);
@@ -374,13 +373,16 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
         const X t = LD(q.t, i), tn = LD(q.t, j), h1 = LD(q.h1, i), h1n = LD(q.h1, j), h2 = LD(q.h2, i);
         X k1 = fx_mul<P>(z2, arg_fx<P>(q.alpha3_opd_k2));
         k1 = fx_mul<P>(k1, fx_add<P>(eps, fx_mul<P>(c, LD(q.q_lookup, i))));
-        k1 = fx_mul<P>(k1, fx_add<P>(fx_add<P>(eopd, t), fx_mul<P>(tn, delta)));
         X k2 = fx_mul<P>(z2n, arg_fx<P>(q.alpha3_k2));
         k2 = fx_mul<P>(k2, fx_add<P>(fx_add<P>(eopd, h1), fx_mul<P>(h2, delta)));
-        k2 = fx_mul<P>(k2, fx_add<P>(fx_add<P>(eopd, h2), fx_mul<P>(h1n, delta)));
-        const X k3 = fx_mul<P>(fx_mul<P>(fx_sub<P, 1>(z2, one), l1), arg_fx<P>(q.alpha4));
+        // k1 * U - k2 * V2, same construction as above: 2p * 4p + 3p * 4p
+        const X k12 = fx_mul2_inl<P>(k1, fx_add<P>(fx_add<P>(eopd, t), fx_mul<P>(tn, delta)), fx_sub_lazy<P, 3>(fx_zero<P>(), k2),
+                                     fx_add<P>(fx_add<P>(eopd, h2), fx_mul<P>(h1n, delta)));
+        // alpha^2 (z1 - 1) l1 + alpha^4 (z2 - 1) l1 = l1 * (alpha^2 (z1 - 1) + alpha^4 (z2 - 1))
+        const X l13 = fx_mul<P>(l1, fx_mul2_inl<P>(fx_sub<P, 1>(z1, one), arg_fx<P>(q.alpha2), fx_sub<P, 1>(z2, one),
+                                                   arg_fx<P>(q.alpha4)));
         const X k4 = fx_mul<P>(fx_mul<P>(t, LD(q.q_table, i)), arg_fx<P>(q.alpha5));
-        acc = fx_add<P>(acc, fx_add<P>(fx_add<P>(fx_sub<P, 2>(k1, k2), k3), k4));   // < 39p, times zh_inv < p: fits R' p
+        acc = fx_add<P>(acc, fx_add<P>(fx_add<P>(k12, l13), k4));   // < 29p in all, times zh_inv < p: fits R' p (70 p on BLS12-381)
     }
 #undef LD
     // quotient_poly.rs:220-224: times zh_coset[i]^-1; x^n - 1 takes 4 values on the 4n coset
