@@ -214,7 +214,6 @@ def test_chained_proofs_with_prefetch(ctxs):
     """zkt_prove_set_next: rounds 1 and 2 of the announced proof are issued behind the current proof's last commitments.
     The bytes must not change - when the announcement is honoured, when a different proof follows, and when another MSM
     call gets in between (which invalidates the early work)."""
-    import torch
     import zkt_plonk_amd as z
     cv = F.BN254
     ctx = ctxs[cv.name]
@@ -227,15 +226,19 @@ def test_chained_proofs_with_prefetch(ctxs):
     ctx.srs_load(srs_arr)
     z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
     a, b, c = cs.wire_evals(cs.n_gates)
-    dev = torch.device("cuda", 0)
-    wires = [torch.from_numpy(K.fr_to_mont(cv, w).view(np.int64)).to(dev) for w in (a, b, c)]
+    wires = []
+    for w in (a, b, c):                       # the witness resident in HBM, through the library's own memory calls
+        arr = K.fr_to_mont(cv, w)
+        d = ctx.alloc(arr.nbytes)
+        ctx.upload(d, arr)
+        wires.append(d)
     pi_pos = sorted(cs.pi)
     pi_vals = K.fr_to_mont(cv, [cs.pi[k] for k in pi_pos])
     table = K.fr_to_mont(cv, cs.table)
     bl = [field_elems(cv.fr.p, 500 + i, P.NUM_BLINDERS) for i in range(4)]
     want = [P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), x).serialize(cv) for x in bl]
-    preps = [ctx.prepare_dev(wires[0].data_ptr(), wires[1].data_ptr(), wires[2].data_ptr(), cs.n_gates, table, pi_pos,
-                             pi_vals, K.fr_to_mont(cv, x)) for x in bl]
+    preps = [ctx.prepare_dev(wires[0], wires[1], wires[2], cs.n_gates, table, pi_pos, pi_vals, K.fr_to_mont(cv, x))
+             for x in bl]
 
     def tr():
         t = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
@@ -252,6 +255,8 @@ def test_chained_proofs_with_prefetch(ctxs):
     assert ctx.prove_prepared(preps[1], tr()) == want[1]
     # and a plain proof afterwards is unaffected
     assert ctx.prove_prepared(preps[3], tr()) == want[3]
+    for d in wires:
+        ctx.free(d)
 
 
 def test_repeated_proofs_reuse_the_table_polynomial(ctxs):
