@@ -57,18 +57,31 @@ __global__ void k_add_blinders(Fe<P>* p, const uint32_t* len, const Fe<P>* bl, i
     fe_store<P>(p + i, fe_sub<P>(cur, b));
 }
 
+// scalars arrive in the 29-bit-limb R' form (H): A * H = A, two terms per reduction
+struct LinCombDev {
+    const void* poly[LC_MAX_TERMS];
+    uint64_t len[LC_MAX_TERMS];
+    uint32_t scalar[LC_MAX_TERMS + 1][9];
+    int nterms;
+};
 template <class P>
-__global__ void k_lincomb(LinCombArgs a, Fe<P>* out, size_t n) {
+__global__ void k_lincomb(LinCombDev a, Fe<P>* out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fe<P> acc = fe_zero<P>();
-    for (int k = 0; k < a.nterms; ++k) {
-        if (i < a.len[k]) {
-            Fe<P> s = arg_fe<P>(a.scalar[k]);
-            acc = fe_add<P>(acc, fe_mul<P>(s, fe_load<P>((const Fe<P>*)a.poly[k] + i)));
+    Fx<P> acc = fx_zero<P>();
+#pragma unroll 1
+    for (int k = 0; k < a.nterms; k += 2) {
+        Fx<P> p[2], sc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool live = k + h < a.nterms && i < a.len[k + h];
+            p[h] = live ? fx_unpack<P>(fe_load<P>((const Fe<P>*)a.poly[live ? k + h : k] + i)) : fx_zero<P>();
+#pragma unroll
+            for (int w = 0; w < 9; ++w) sc[h].l[w] = a.scalar[k + h][w];
         }
+        acc = fx_add<P>(acc, fx_mul2_inl<P>(p[0], sc[0], p[1], sc[1]));   // < 2p each: at most LC_MAX_TERMS p in all
     }
-    fe_store<P>(out + i, acc);
+    fe_store<P>(out + i, fx_pack<P>(fx_canon<P>(acc)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,7 +699,16 @@ int poly_add_blinders(zkt_ctx* c, void* p, const uint32_t* d_len, const void* d_
 }
 
 template <class P> static int lincomb_t(zkt_ctx* c, const LinCombArgs& a, void* out, size_t n) {
-    hipLaunchKernelGGL(k_lincomb<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, a, (Fe<P>*)out, n);
+    static_assert(LC_MAX_TERMS <= 32, "the lazy sum of the terms must stay below 2^6 p");
+    LinCombDev d{};
+    d.nterms = a.nterms;
+    for (int k = 0; k < a.nterms; ++k) {
+        d.poly[k] = a.poly[k];
+        d.len[k] = a.len[k];
+        const Fx<P> h = fx_cond_sub_p<P>(fx_from_ark<P>(host_fe<P>(a.scalar[k])));
+        for (int w = 0; w < 9; ++w) d.scalar[k][w] = h.l[w];
+    }
+    hipLaunchKernelGGL(k_lincomb<P>, dim3(nblocks(n)), dim3(256), 0, c->stream, d, (Fe<P>*)out, n);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
