@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built libraries are not tracked by git: on a fresh checkout build them first (hipcc cross-compiles gfx950
+    without a GPU).  Nothing is built when they are already there."""
+    lib = os.path.join(ROOT, "zkt-plonk_amd", "libzkt_plonk_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "vectors.json")) as f:
