@@ -92,7 +92,7 @@ int zkt_domain_group_gen(zkt_ctx* ctx, int log_n, uint64_t* out4);
 /* ---- Commitment seam: PC: HomomorphicCommitment<F> = KZG10<E> (commitment.rs:10-46) --------- */
 /* Loads `count` G1 powers (ck.powers_of_g of SonicKZG10's CommitterKey, produced by PC::trim at
  * plonk.rs:79-85) and precomputes the window multiples used by the MSM.  One-time per key.  The
- * prover never uses more than n + 6 powers, so loading n + 8 of the 4n + 1 the reference keeps is
+ * prover never commits to more than n + 7 coefficients (the opening witnesses), so loading n + 8 of the 4n + 1 powers the reference keeps is
  * enough.  Replaces nothing at run time: it is the device-resident form of `ck`. */
 int zkt_srs_load(zkt_ctx* ctx, const uint64_t* g1_xy_mont, size_t count);
 int zkt_srs_load_dev(zkt_ctx* ctx, const void* d_g1_xy_mont, size_t count);

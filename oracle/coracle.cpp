@@ -673,6 +673,329 @@ extern "C" int orc_fq_convert(int curve, int to_montgomery, const u64* in, size_
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The O(n) loops of the prover (plonk-core/src/proof_system/prove.rs:59-470), restated on Montgomery
+// arrays so that whole proofs at n = 2^14 .. 2^22 are available as the byte-exact check of the GPU
+// path.  Each function is pinned against its big-integer twin in oracle/plonk.py at n <= 4096
+// (tests/test_coracle.py).  Field arithmetic is exact, so evaluation order (batched inversions,
+// OpenMP chunking) cannot change a result.
+// ---------------------------------------------------------------------------------------------
+static inline Fr fr_load(const u64* p) {
+    Fr r;
+    memcpy(r.v, p, 32);
+    return r;
+}
+static inline void fr_store(u64* p, const Fr& a) { memcpy(p, a.v, 32); }
+static inline Fr fr_one(const FpParams<4>& P) {
+    Fr r;
+    memcpy(r.v, P.r, 32);
+    return r;
+}
+static inline Fr fr_pow_u64(const Fr& a, u64 e, const FpParams<4>& P) {
+    u64 ee[1] = {e};
+    return fpow<4>(a, ee, 1, P);
+}
+
+// Montgomery's trick per chunk; returns false when some element is zero (the reference unwraps an inverse there)
+static bool batch_inverse(Fr* v, size_t n, const FpParams<4>& P) {
+    const size_t CH = 4096;
+    size_t nchunks = (n + CH - 1) / CH;
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (long c = 0; c < (long)nchunks; ++c) {
+        size_t lo = c * CH, hi = std::min(n, lo + CH);
+        std::vector<Fr> pre(hi - lo);
+        Fr acc = fr_one(P);
+        for (size_t i = lo; i < hi; ++i) {
+            if (fis_zero<4>(v[i])) bad = 1;
+            pre[i - lo] = acc;
+            acc = fmul<4>(acc, v[i], P);
+        }
+        if (bad) continue;
+        Fr inv = finv<4>(acc, P);
+        for (size_t i = hi; i-- > lo;) {
+            Fr t = fmul<4>(inv, pre[i - lo], P);
+            inv = fmul<4>(inv, v[i], P);
+            v[i] = t;
+        }
+    }
+    return !bad;
+}
+
+// out[i] = w^i * scale, i < n (domain elements / coset points)
+static void fill_powers(Fr* out, size_t n, const Fr& w, const Fr& scale, const FpParams<4>& P) {
+    const size_t CH = 4096;
+    size_t nchunks = (n + CH - 1) / CH;
+#pragma omp parallel for schedule(static)
+    for (long c = 0; c < (long)nchunks; ++c) {
+        size_t lo = c * CH, hi = std::min(n, lo + CH);
+        Fr cur = fmul<4>(fr_pow_u64(w, lo, P), scale, P);
+        for (size_t i = lo; i < hi; ++i) {
+            out[i] = cur;
+            cur = fmul<4>(cur, w, P);
+        }
+    }
+}
+
+// kind 0: domain.elements() (util.rs:27-50); kind 1: coset points g * w^i (keys/mod.rs:110-113 x_coset)
+extern "C" int orc_domain_points(int curve, int log_n, int kind, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FrInfo& I = FR_INFO[curve];
+    const FpParams<4>& P = *I.P;
+    if (log_n < 0 || log_n > I.two_adicity) return 2;
+    Fr w = fr_root_of_unity(I, log_n);
+    Fr scale = kind ? from_u64<4>(I.generator, P) : fr_one(P);
+    fill_powers((Fr*)out, (size_t)1 << log_n, w, scale, P);
+    return 0;
+}
+
+// elementwise: op 0 add, 1 sub, 2 mul (prove.rs:157-161 f = q_lookup . c uses the product)
+extern "C" int orc_fr_vec_op(int curve, int op, const u64* a, const u64* b, size_t n, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FpParams<4>& P = *FR_INFO[curve].P;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+        Fr x = fr_load(a + 4 * i), y = fr_load(b + 4 * i);
+        Fr r = op == 0 ? fadd<4>(x, y, P) : op == 1 ? fsub<4>(x, y, P) : fmul<4>(x, y, P);
+        fr_store(out + 4 * i, r);
+    }
+    return 0;
+}
+
+// permutation/mod.rs:181-254 compute_permutation_poly, evaluation form (before the iFFT at :256).
+// z[0] = 1, z[i+1] = z[i] * num_i / den_i for i < n - 1.  Returns 6 when a denominator is zero.
+extern "C" int orc_z1_evals(int curve, int log_n, const u64* beta_, const u64* gamma_, const u64* a, const u64* b,
+                            const u64* c, const u64* s1, const u64* s2, const u64* s3, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FrInfo& I = FR_INFO[curve];
+    const FpParams<4>& P = *I.P;
+    size_t n = (size_t)1 << log_n;
+    Fr beta = fr_load(beta_), gamma = fr_load(gamma_);
+    Fr k1 = from_u64<4>(7, P), k2 = from_u64<4>(13, P);   // permutation/constants.rs:13-20
+    std::vector<Fr> roots(n), num(n), den(n);
+    fill_powers(roots.data(), n, fr_root_of_unity(I, log_n), fr_one(P), P);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)(n - 1); ++i) {
+        Fr br = fmul<4>(beta, roots[i], P);
+        Fr ai = fr_load(a + 4 * i), bi = fr_load(b + 4 * i), ci = fr_load(c + 4 * i);
+        Fr ag = fadd<4>(ai, gamma, P), bg = fadd<4>(bi, gamma, P), cg = fadd<4>(ci, gamma, P);
+        Fr nu = fmul<4>(fadd<4>(br, ag, P), fadd<4>(fmul<4>(k1, br, P), bg, P), P);
+        num[i] = fmul<4>(nu, fadd<4>(fmul<4>(k2, br, P), cg, P), P);
+        Fr de = fmul<4>(fadd<4>(fmul<4>(beta, fr_load(s1 + 4 * i), P), ag, P),
+                        fadd<4>(fmul<4>(beta, fr_load(s2 + 4 * i), P), bg, P), P);
+        den[i] = fmul<4>(de, fadd<4>(fmul<4>(beta, fr_load(s3 + 4 * i), P), cg, P), P);
+    }
+    if (n > 1 && !batch_inverse(den.data(), n - 1, P)) return 6;
+    Fr state = fr_one(P);
+    fr_store(out, state);
+    for (size_t i = 0; i + 1 < n; ++i) {
+        state = fmul<4>(state, fmul<4>(num[i], den[i], P), P);
+        fr_store(out + 4 * (i + 1), state);
+    }
+    return 0;
+}
+
+// lookup/mod.rs:94-151 compute_lookup_permutation_poly, evaluation form (before the iFFT at :153)
+extern "C" int orc_z2_evals(int curve, int log_n, const u64* delta_, const u64* epsilon_, const u64* f, const u64* t,
+                            const u64* h1, const u64* h2, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FpParams<4>& P = *FR_INFO[curve].P;
+    size_t n = (size_t)1 << log_n;
+    Fr delta = fr_load(delta_), eps = fr_load(epsilon_);
+    Fr opd = fadd<4>(fr_one(P), delta, P), eopd = fmul<4>(eps, opd, P);
+    std::vector<Fr> num(n), den(n);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)(n - 1); ++i) {
+        Fr ti = fr_load(t + 4 * i), tn = fr_load(t + 4 * (i + 1));
+        Fr h1i = fr_load(h1 + 4 * i), h1n = fr_load(h1 + 4 * (i + 1)), h2i = fr_load(h2 + 4 * i);
+        Fr nu = fmul<4>(opd, fadd<4>(eps, fr_load(f + 4 * i), P), P);
+        num[i] = fmul<4>(nu, fadd<4>(fadd<4>(fmul<4>(delta, tn, P), eopd, P), ti, P), P);
+        den[i] = fmul<4>(fadd<4>(fadd<4>(fmul<4>(delta, h2i, P), eopd, P), h1i, P),
+                         fadd<4>(fadd<4>(fmul<4>(delta, h1n, P), eopd, P), h2i, P), P);
+    }
+    if (n > 1 && !batch_inverse(den.data(), n - 1, P)) return 6;
+    Fr state = fr_one(P);
+    fr_store(out, state);
+    for (size_t i = 0; i + 1 < n; ++i) {
+        state = fmul<4>(state, fmul<4>(num[i], den[i], P), P);
+        fr_store(out + 4 * (i + 1), state);
+    }
+    return 0;
+}
+
+// proof_system/quotient_poly.rs:98-224 with keys/arithmetic.rs:67-81, keys/permutation.rs:97-137,
+// keys/lookup.rs:81-122.  epk: q_m q_l q_r q_o q_c q_lookup q_table sigma1 sigma2 sigma3 x zh l_1;
+// wit: a b c pi z1 z2 t h1 h2; all vectors are 4n coset evaluations; "next" = index + 4 (quotient_poly.rs:52-94).
+extern "C" int orc_quotient_evals(int curve, int log_n, const u64* ch, const u64* const* epk, const u64* const* wit,
+                                  u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FpParams<4>& P = *FR_INFO[curve].P;
+    size_t N = (size_t)4 << log_n;
+    Fr alpha = fr_load(ch), beta = fr_load(ch + 4), gamma = fr_load(ch + 8), delta = fr_load(ch + 12),
+       eps = fr_load(ch + 16);
+    Fr one = fr_one(P);
+    Fr a2 = fmul<4>(alpha, alpha, P), a3 = fmul<4>(a2, alpha, P), a4 = fmul<4>(a3, alpha, P), a5 = fmul<4>(a4, alpha, P);
+    Fr opd = fadd<4>(delta, one, P), eopd = fmul<4>(eps, opd, P);
+    Fr k1 = from_u64<4>(7, P), k2 = from_u64<4>(13, P);
+    Fr nalpha = fneg<4>(alpha, P), na3 = fneg<4>(a3, P);
+    std::vector<Fr> zhinv(N);
+    memcpy(zhinv.data(), epk[11], N * 32);
+    if (!batch_inverse(zhinv.data(), N, P)) return 6;
+    enum { QM, QL, QR, QO, QC, QLK, QT, S1, S2, S3, X, ZH, L1 };
+    enum { A, B, C, PI, Z1, Z2, T, H1, H2 };
+#define E(k) fr_load(epk[k] + 4 * i)
+#define W(k) fr_load(wit[k] + 4 * i)
+#define WN(k) fr_load(wit[k] + 4 * j)
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)N; ++i) {
+        size_t j = ((size_t)i + 4) % N;
+        Fr a = W(A), b = W(B), c = W(C);
+        Fr arith = fmul<4>(fmul<4>(a, b, P), E(QM), P);
+        arith = fadd<4>(arith, fmul<4>(a, E(QL), P), P);
+        arith = fadd<4>(arith, fmul<4>(b, E(QR), P), P);
+        arith = fadd<4>(arith, fmul<4>(c, E(QO), P), P);
+        arith = fadd<4>(fadd<4>(arith, E(QC), P), W(PI), P);
+        Fr ag = fadd<4>(a, gamma, P), bg = fadd<4>(b, gamma, P), cg = fadd<4>(c, gamma, P);
+        Fr bx = fmul<4>(beta, E(X), P);
+        Fr z1 = W(Z1), z1n = WN(Z1), z2 = W(Z2), z2n = WN(Z2);
+        Fr p1 = fmul<4>(fmul<4>(alpha, z1, P), fadd<4>(bx, ag, P), P);
+        p1 = fmul<4>(fmul<4>(p1, fadd<4>(fmul<4>(bx, k1, P), bg, P), P), fadd<4>(fmul<4>(bx, k2, P), cg, P), P);
+        Fr p2 = fmul<4>(fmul<4>(nalpha, z1n, P), fadd<4>(fmul<4>(beta, E(S1), P), ag, P), P);
+        p2 = fmul<4>(fmul<4>(p2, fadd<4>(fmul<4>(beta, E(S2), P), bg, P), P), fadd<4>(fmul<4>(beta, E(S3), P), cg, P), P);
+        Fr l1 = E(L1);
+        Fr p3 = fmul<4>(fmul<4>(fsub<4>(z1, one, P), l1, P), a2, P);
+        Fr t = W(T), tn = WN(T), h1 = W(H1), h1n = WN(H1), h2 = W(H2);
+        Fr k1_ = fmul<4>(fmul<4>(fmul<4>(a3, z2, P), opd, P), fadd<4>(eps, fmul<4>(E(QLK), c, P), P), P);
+        k1_ = fmul<4>(k1_, fadd<4>(fadd<4>(eopd, t, P), fmul<4>(delta, tn, P), P), P);
+        Fr k2_ = fmul<4>(fmul<4>(na3, z2n, P), fadd<4>(fadd<4>(eopd, h1, P), fmul<4>(delta, h2, P), P), P);
+        k2_ = fmul<4>(k2_, fadd<4>(fadd<4>(eopd, h2, P), fmul<4>(delta, h1n, P), P), P);
+        Fr k3_ = fmul<4>(fmul<4>(a4, fsub<4>(z2, one, P), P), l1, P);
+        Fr k4_ = fmul<4>(fmul<4>(a5, E(QT), P), t, P);
+        Fr tot = fadd<4>(fadd<4>(fadd<4>(arith, p1, P), fadd<4>(p2, p3, P), P),
+                         fadd<4>(fadd<4>(k1_, k2_, P), fadd<4>(k3_, k4_, P), P), P);
+        fr_store(out + 4 * i, fmul<4>(tot, zhinv[i], P));   // quotient_poly.rs:220-224
+    }
+#undef E
+#undef W
+#undef WN
+    return 0;
+}
+
+// lookup/multiset.rs:103-146 combine_split: counters in first-insertion order of t (IndexMap), every element of
+// f must already be a key (Error::ElementNotIndexedInTable -> 8); halves alternate for odd counts.
+struct Key32 {
+    u64 v[4];
+    bool operator==(const Key32& o) const { return !memcmp(v, o.v, 32); }
+};
+struct Key32Hash {
+    size_t operator()(const Key32& k) const {
+        u64 h = k.v[0] * 0x9E3779B97F4A7C15ULL;
+        h ^= (k.v[1] + 0x7F4A7C15ULL + (h << 6) + (h >> 2));
+        h ^= (k.v[2] * 0xBF58476D1CE4E5B9ULL) ^ (k.v[3] * 0x94D049BB133111EBULL);
+        return (size_t)h;
+    }
+};
+#include <unordered_map>
+extern "C" int orc_combine_split(const u64* t, size_t nt, const u64* f, size_t nf, u64* h1, u64* h2, size_t* lens) {
+    std::unordered_map<Key32, size_t, Key32Hash> idx;
+    idx.reserve(1024);
+    std::vector<Key32> keys;
+    std::vector<size_t> counts;
+    for (size_t i = 0; i < nt; ++i) {
+        Key32 k;
+        memcpy(k.v, t + 4 * i, 32);
+        auto it = idx.find(k);
+        if (it == idx.end()) {
+            idx.emplace(k, keys.size());
+            keys.push_back(k);
+            counts.push_back(1);
+        } else {
+            ++counts[it->second];
+        }
+    }
+    for (size_t i = 0; i < nf; ++i) {
+        Key32 k;
+        memcpy(k.v, f + 4 * i, 32);
+        auto it = idx.find(k);
+        if (it == idx.end()) return 8;
+        ++counts[it->second];
+    }
+    size_t e = 0, o = 0;
+    bool parity = false;
+    for (size_t k = 0; k < keys.size(); ++k) {
+        size_t half = counts[k] / 2;
+        for (size_t r = 0; r < half; ++r) {
+            memcpy(h1 + 4 * e++, keys[k].v, 32);
+            memcpy(h2 + 4 * o++, keys[k].v, 32);
+        }
+        if (counts[k] & 1) {
+            if (parity) {
+                memcpy(h2 + 4 * o++, keys[k].v, 32);
+                parity = false;
+            } else {
+                memcpy(h1 + 4 * e++, keys[k].v, 32);
+                parity = true;
+            }
+        }
+    }
+    lens[0] = e;
+    lens[1] = o;
+    return 0;
+}
+
+// out[i] = sum_k scalars[k] * polys[k][i] for i < out_len (coefficients beyond lens[k] are zero): the scaled sums of
+// linearization_poly.rs:19-121 and of the opening combinations (prove.rs:381-451)
+extern "C" int orc_lincomb(int curve, int k, const u64* const* polys, const size_t* lens, const u64* scalars,
+                           size_t out_len, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FpParams<4>& P = *FR_INFO[curve].P;
+    std::vector<Fr> s(k);
+    for (int j = 0; j < k; ++j) s[j] = fr_load(scalars + 4 * j);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)out_len; ++i) {
+        Fr acc{};
+        for (int j = 0; j < k; ++j)
+            if ((size_t)i < lens[j]) acc = fadd<4>(acc, fmul<4>(s[j], fr_load(polys[j] + 4 * i), P), P);
+        fr_store(out + 4 * i, acc);
+    }
+    return 0;
+}
+
+// DensePolynomial::evaluate (Horner per chunk, chunks combined with powers of the point)
+extern "C" int orc_poly_eval(int curve, const u64* poly, size_t len, const u64* point, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FpParams<4>& P = *FR_INFO[curve].P;
+    Fr x = fr_load(point);
+    const size_t CH = 8192;
+    size_t nchunks = (len + CH - 1) / CH;
+    std::vector<Fr> part(nchunks);
+#pragma omp parallel for schedule(static)
+    for (long c = 0; c < (long)nchunks; ++c) {
+        size_t lo = c * CH, hi = std::min(len, lo + CH);
+        Fr acc{};
+        for (size_t i = hi; i-- > lo;) acc = fadd<4>(fmul<4>(acc, x, P), fr_load(poly + 4 * i), P);
+        part[c] = fmul<4>(acc, fr_pow_u64(x, lo, P), P);
+    }
+    Fr tot{};
+    for (size_t c = 0; c < nchunks; ++c) tot = fadd<4>(tot, part[c], P);
+    fr_store(out, tot);
+    return 0;
+}
+
+// kzg10::open witness polynomial: (p(X) - p(z)) / (X - z), the remainder dropped (call sites prove.rs:381-451);
+// out receives len - 1 coefficients
+extern "C" int orc_div_linear(int curve, const u64* poly, size_t len, const u64* z_, u64* out) {
+    if (curve < 0 || curve > 1) return 1;
+    const FpParams<4>& P = *FR_INFO[curve].P;
+    Fr z = fr_load(z_);
+    Fr carry{};
+    for (size_t i = len; i-- > 1;) {
+        carry = fadd<4>(fr_load(poly + 4 * i), fmul<4>(z, carry, P), P);
+        fr_store(out + 4 * (i - 1), carry);
+    }
+    return 0;
+}
+
 // expose parameter tables so the tests can pin them against Python big integers
 extern "C" int orc_params(int which, u64* out /* p, inv, r, r2 flattened */) {
     auto dump4 = [&](const FpParams<4>& P) {

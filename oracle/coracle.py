@@ -53,6 +53,17 @@ def lib():
         L.orc_fr_convert.argtypes = [ctypes.c_int, ctypes.c_int, u64p, ctypes.c_size_t, u64p]
         L.orc_fq_convert.argtypes = [ctypes.c_int, ctypes.c_int, u64p, ctypes.c_size_t, u64p]
         L.orc_params.argtypes = [ctypes.c_int, u64p]
+        pp = ctypes.POINTER(u64p)
+        szp = ctypes.POINTER(ctypes.c_size_t)
+        L.orc_domain_points.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p]
+        L.orc_fr_vec_op.argtypes = [ctypes.c_int, ctypes.c_int, u64p, u64p, ctypes.c_size_t, u64p]
+        L.orc_z1_evals.argtypes = [ctypes.c_int, ctypes.c_int] + [u64p] * 9
+        L.orc_z2_evals.argtypes = [ctypes.c_int, ctypes.c_int] + [u64p] * 7
+        L.orc_quotient_evals.argtypes = [ctypes.c_int, ctypes.c_int, u64p, pp, pp, u64p]
+        L.orc_combine_split.argtypes = [u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p, u64p, szp]
+        L.orc_lincomb.argtypes = [ctypes.c_int, ctypes.c_int, pp, szp, u64p, ctypes.c_size_t, u64p]
+        L.orc_poly_eval.argtypes = [ctypes.c_int, u64p, ctypes.c_size_t, u64p, u64p]
+        L.orc_div_linear.argtypes = [ctypes.c_int, u64p, ctypes.c_size_t, u64p, u64p]
         L.orc_num_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         L.orc_set_threads(int(os.environ.get("ORACLE_THREADS", _cpu_share())))  # env vars are read too late once
@@ -151,6 +162,115 @@ def srs_mont(cv: Curve, tau: int, count: int) -> np.ndarray:
     out = np.empty((count, 2 * L), dtype=np.uint64)
     assert lib().orc_srs(cv.curve_id, _p(gx), _p(gy), _p(t), count, _p(out)) == 0
     return out
+
+
+# ---- the prover's O(n) loops on Montgomery arrays (pinned against oracle/plonk.py in tests/test_coracle.py) ----
+def _arr(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+
+
+def _ptrs(arrs):
+    return (ctypes.POINTER(ctypes.c_uint64) * len(arrs))(*[_p(a) for a in arrs])
+
+
+def domain_points(cv: Curve, log_n: int, coset: bool = False) -> np.ndarray:
+    out = np.empty((1 << log_n, 4), dtype=np.uint64)
+    assert lib().orc_domain_points(cv.curve_id, log_n, int(coset), _p(out)) == 0
+    return out
+
+
+def vec_op(cv: Curve, op: str, a, b) -> np.ndarray:
+    a, b = _arr(a), _arr(b)
+    assert a.shape == b.shape
+    out = np.empty_like(a)
+    assert lib().orc_fr_vec_op(cv.curve_id, {"add": 0, "sub": 1, "mul": 2}[op], _p(a), _p(b), a.shape[0], _p(out)) == 0
+    return out
+
+
+def z1_evals(cv: Curve, log_n: int, beta, gamma, a, b, c, s1, s2, s3) -> np.ndarray:
+    """permutation/mod.rs:181-254; beta, gamma: (4,) Montgomery limbs; vectors: (n, 4)."""
+    out = np.empty((1 << log_n, 4), dtype=np.uint64)
+    vs = [_arr(x) for x in (a, b, c, s1, s2, s3)]
+    assert all(v.shape[0] == 1 << log_n for v in vs)
+    rc = lib().orc_z1_evals(cv.curve_id, log_n, _p(_arr(beta)), _p(_arr(gamma)), *[_p(v) for v in vs], _p(out))
+    if rc:
+        raise ZeroDivisionError("zero denominator in the permutation grand product")
+    return out
+
+
+def z2_evals(cv: Curve, log_n: int, delta, epsilon, f, t, h1, h2) -> np.ndarray:
+    """lookup/mod.rs:94-151."""
+    out = np.empty((1 << log_n, 4), dtype=np.uint64)
+    vs = [_arr(x) for x in (f, t, h1, h2)]
+    assert all(v.shape[0] == 1 << log_n for v in vs)
+    rc = lib().orc_z2_evals(cv.curve_id, log_n, _p(_arr(delta)), _p(_arr(epsilon)), *[_p(v) for v in vs], _p(out))
+    if rc:
+        raise ZeroDivisionError("zero denominator in the lookup grand product")
+    return out
+
+
+EPK_ORDER = ("q_m", "q_l", "q_r", "q_o", "q_c", "q_lookup", "q_table", "sigma1", "sigma2", "sigma3", "x", "zh", "l_1")
+WIT_ORDER = ("a", "b", "c", "pi", "z1", "z2", "t", "h1", "h2")
+
+
+def quotient_evals(cv: Curve, log_n: int, ch, epk: dict, wit: dict) -> np.ndarray:
+    """quotient_poly.rs:98-224; ch: (5, 4) alpha beta gamma delta epsilon; epk / wit: name -> (4n, 4)."""
+    N = 4 << log_n
+    e = [_arr(epk[k]) for k in EPK_ORDER]
+    w = [_arr(wit[k]) for k in WIT_ORDER]
+    assert all(v.shape[0] == N for v in e + w)
+    out = np.empty((N, 4), dtype=np.uint64)
+    rc = lib().orc_quotient_evals(cv.curve_id, log_n, _p(_arr(ch).reshape(-1)), _ptrs(e), _ptrs(w), _p(out))
+    if rc:
+        raise ZeroDivisionError("vanishing polynomial is zero on the coset")
+    return out
+
+
+def combine_split(t, f):
+    """lookup/multiset.rs:103-146 on Montgomery arrays -> (h1, h2)."""
+    t, f = _arr(t), _arr(f)
+    h1 = np.empty((t.shape[0] + f.shape[0], 4), dtype=np.uint64)
+    h2 = np.empty_like(h1)
+    lens = (ctypes.c_size_t * 2)()
+    rc = lib().orc_combine_split(_p(t), t.shape[0], _p(f), f.shape[0], _p(h1), _p(h2), lens)
+    if rc:
+        raise KeyError("ElementNotIndexedInTable")
+    return h1[:lens[0]].copy(), h2[:lens[1]].copy()
+
+
+def lincomb(cv: Curve, polys, scalars, out_len: int) -> np.ndarray:
+    """sum_k scalars[k] * polys[k], zero padded / cut to out_len coefficients."""
+    ps = [_arr(q) for q in polys]
+    keep = [q if q.shape[0] else np.zeros((1, 4), dtype=np.uint64) for q in ps]
+    lens = (ctypes.c_size_t * len(ps))(*[q.shape[0] for q in ps])
+    sc = _arr(scalars)
+    assert sc.shape[0] == len(ps)
+    out = np.empty((out_len, 4), dtype=np.uint64)
+    assert lib().orc_lincomb(cv.curve_id, len(ps), _ptrs(keep), lens, _p(sc.reshape(-1)), out_len, _p(out)) == 0
+    return out
+
+
+def poly_eval(cv: Curve, poly, point) -> np.ndarray:
+    poly = _arr(poly)
+    out = np.zeros(4, dtype=np.uint64)
+    if poly.shape[0]:
+        assert lib().orc_poly_eval(cv.curve_id, _p(poly), poly.shape[0], _p(_arr(point)), _p(out)) == 0
+    return out
+
+
+def div_linear(cv: Curve, poly, z) -> np.ndarray:
+    """(p(X) - p(z)) / (X - z): len - 1 coefficients."""
+    poly = _arr(poly)
+    out = np.empty((max(poly.shape[0] - 1, 0), 4), dtype=np.uint64)
+    if poly.shape[0] > 1:
+        assert lib().orc_div_linear(cv.curve_id, _p(poly), poly.shape[0], _p(_arr(z)), _p(out)) == 0
+    return out
+
+
+def trim_len(arr) -> int:
+    """DensePolynomial::from_coefficients_vec: length after stripping trailing zero coefficients."""
+    nz = np.flatnonzero(_arr(arr).any(axis=1))
+    return int(nz[-1]) + 1 if nz.size else 0
 
 
 def params(which: int) -> dict:

@@ -207,23 +207,26 @@ def test_circuit(cv: Curve, a=2, b=3, d=10, e=True, size=100) -> ConstraintSyste
 
 
 def synthetic_circuit(cv: Curve, n_gates: int, table_size: int, seed: int = 1,
-                      n_public: int = 7, lookup_every: int = 16) -> ConstraintSystem:
+                      n_public: int = 7, lookup_every: int = 16, value_seed: Optional[int] = None) -> ConstraintSystem:
     """Withdraw-shaped synthetic trace: random satisfying add/mul/linear
     gates chained through copy constraints, a lookup row every ``lookup_every`` gates,
     ``n_public`` public inputs.  Witness synthesis is out of scope; only the row count and the
-    constraint mix matter to the prover."""
+    constraint mix matter to the prover.  With ``value_seed`` the witness (free values, table contents, looked-up
+    entries, hence the public inputs) is drawn from its own generator: circuits of one ``seed`` then share their
+    structure (selectors, copy constraints) and differ in everything a prover is handed per proof."""
     import random
     rnd = random.Random(seed)
+    vrnd = rnd if value_seed is None else random.Random(value_seed)
     p = cv.fr.p
-    table = [rnd.randrange(p) for _ in range(min(table_size, 64))]
+    table = [vrnd.randrange(p) for _ in range(min(table_size, 64))]
     cs = ConstraintSystem(cv, table, table_size)
     tbl = cs.table
-    live = [cs.assign_variable(rnd.randrange(p)) for _ in range(4)]
+    live = [cs.assign_variable(vrnd.randrange(p)) for _ in range(4)]
     while cs.n_gates < n_gates - n_public:
         g = cs.n_gates
         x, y = rnd.choice(live), rnd.choice(live)
         if lookup_every and g % lookup_every == lookup_every - 1:
-            t = cs.assign_variable(tbl[rnd.randrange(len(tbl))])
+            t = cs.assign_variable(tbl[vrnd.randrange(len(tbl))])
             cs.lookup_constrain(t)
             live.append(t)
         elif g % 3 == 0:

@@ -171,9 +171,9 @@ def test_msm_sharded_by_index_range(cv, shards, ctxs):
     assert ginf == finf == winf and np.array_equal(got, full) and np.array_equal(got, want)
 
 
-def test_msm_full_size_2_20(ctxs):
-    """BASELINE config 3: 2^20 scalars/points, bit-exact commitment (BN254), plus linearity."""
-    cv = F.BN254
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_msm_full_size_2_20(cv, ctxs):
+    """BASELINE config 2: 2^20 scalars/points, bit-exact commitment on both curves, plus linearity."""
     ctx = ctxs[cv.name]
     n = 1 << 20
     ctx.srs_generate(0x5EED, n)

@@ -67,6 +67,8 @@ def test_ntt_matches_oracle_every_size(cv, log_n, ctxs):
     lens = sorted({n, max(1, n - 3), max(1, n // 4 + 3) if n >= 4 else n})
     if log_n >= 17:
         lens = [n // 4 + 3]   # the prover's shape: <= n/4 + 3 coefficients on the 4x domain
+    if log_n == 20:
+        lens = [n // 4 + 3, n]   # BASELINE.json configs[1]: the literal full-length 2^20 input, every coefficient compared
     for in_len in lens:
         x = rand_fr(rng, in_len)
         for name, inv, cos in VARIANTS:

@@ -162,21 +162,13 @@ def test_witness_gather_on_the_device(ctxs):
     assert e.value.code == 1
 
 
-@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
-def test_full_size_proof_is_accepted_by_the_verifier(cv, ctxs):
-    """BASELINE.json configs[3] (BN254, n = 2^20, TABLE_SIZE 1024, 7 public inputs): the workload bench.py times; and
-    the same size on BLS12-381 (configs[4] is this path at 2^22, too slow to set up inside a test).
-    The oracle cannot prove at this size in test time, so the pin is size independent: the oracle's verifier
-    (proof.rs:285-503, pairing replaced by the trapdoor identity) accepts the GPU proof under the GPU-made VerifierKey,
-    one of whose commitments is checked against the CPU oracle; a flipped evaluation is rejected."""
-    import zkt_plonk_amd as z
+def _bench_workload(z, ctx, cv, log_n, tau):
+    """bench.py's workload (BASELINE.json configs[3] shape: TABLE_SIZE 1024, 7 public inputs, 2^log_n rows) set up on
+    the device; returns what both sides need: Montgomery arrays, the SRS the GPU generated, the GPU-made VerifierKey."""
     import bench as B
-    ctx = ctxs[cv.name]
-    fld = B.FIELDS[cv.name]
-    log_n, n = 20, 1 << 20
-    tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
+    n = 1 << log_n
     ctx.srs_generate(tau, n + 8)
-    circ = B.synthetic_circuit(fld, log_n)
+    circ = B.synthetic_circuit(B.FIELDS[cv.name], log_n)
     evals = {name: K.fr_to_mont(cv, circ["sel"][name]) for name in z.PK_ORDER}
     prover, commits = z.GpuProver.setup(ctx, log_n, evals)
     L = cv.fq.limbs64
@@ -187,28 +179,78 @@ def test_full_size_proof_is_accepted_by_the_verifier(cv, ctxs):
         xy, inf = commits[name]
         pts[name] = None if inf else (sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % q,
                                       sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % q)
-    # one VerifierKey commitment against the CPU port: q_c = commit(ifft(q_c evaluations))
+    gates = circ["gates"]
+    pi_pos = sorted(circ["pi"])
+    w = dict(a=K.fr_to_mont(cv, circ["a"][:gates]), b=K.fr_to_mont(cv, circ["b"][:gates]),
+             c=K.fr_to_mont(cv, circ["c"][:gates]), table=K.fr_to_mont(cv, circ["table"]), pi=circ["pi"], pi_pos=pi_pos,
+             pi_vals=K.fr_to_mont(cv, [circ["pi"][k] for k in pi_pos]))
+    vk = P.VerifierKey(n, [pow(cv.fr.root_of_unity(n), i, cv.fr.p) for i in pi_pos], pts)
+    return evals, w, vk
+
+
+def _gpu_prove_arrays(z, ctx, cv, w, vk, blinders):
+    tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * cv.fq.limbs64)
+    z.seed_transcript(tr, vk.n, vk.commits)
+    return ctx.prove(w["a"], w["b"], w["c"], w["table"], w["pi_pos"], w["pi_vals"], K.fr_to_mont(cv, blinders), tr)
+
+
+@pytest.mark.parametrize("cvname,log_n", [("bn254", 14), ("bls12_381", 14), ("bn254", 20)])
+def test_headline_configs_proof_bytes_equal_cpu_oracle(cvname, log_n, ctxs):
+    """BASELINE.json configs[0] (BN254, n = 2^14) and configs[3] (BN254, n = 2^20: the workload bench.py times), plus
+    BLS12-381 at 2^14: the GPU proof equals, byte for byte, the proof of the CPU oracle's array prover
+    (oracle/fastplonk.py, pinned to the big-integer restatement of prove.rs:59-470 in tests/test_coracle.py) on the
+    same SRS, witness, public inputs and blinders.  VerifierKey commitments: all ten at 2^14, two at 2^20."""
+    import zkt_plonk_amd as z
+    from oracle import fastplonk as FP
+    cv = F.CURVES[cvname]
+    ctx = ctxs[cv.name]
+    n = 1 << log_n
+    tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
+    evals, w, vk = _bench_workload(z, ctx, cv, log_n, tau)
+    srs = ctx.srs_download(0, n + 8)
+    assert np.array_equal(srs[:64], K.srs_mont(cv, tau, 64))
+    keys = FP.setup(cv, srs, log_n, evals, commitments=log_n <= 14)
+    if log_n <= 14:
+        assert keys.commits == vk.commits
+    else:
+        for name in ("q_c", "sigma3"):
+            assert FP.commit(cv, srs, keys.pk[name]) == vk.commits[name], name
+    blinders = field_elems(cv.fr.p, 2020 + log_n, P.NUM_BLINDERS)
+    got = _gpu_prove_arrays(z, ctx, cv, w, vk, blinders)
+    want = FP.prove(cv, srs, keys, w["a"], w["b"], w["c"], w["table"], w["pi"], P.new_seeded_transcript(cv, vk), blinders)
+    assert len(got) == (802 if cv.name == "bn254" else 1010)
+    assert got == want
+    pis = [w["pi"][k] for k in w["pi_pos"]]
+    assert P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), pis)
+
+
+@pytest.mark.parametrize("cvname,log_n", [("bls12_381", 20), ("bls12_381", 22)])
+def test_large_bls12_381_proofs_are_accepted_by_the_verifier(cvname, log_n, ctxs):
+    """BASELINE.json configs[4], single-GPU leg: BLS12-381 at n = 2^22 (and 2^20).  A CPU proof at this size exceeds test
+    time, so the pin is size independent: the oracle's verifier (proof.rs:285-503, pairing replaced by the trapdoor
+    identity) accepts the GPU proof under the GPU-made VerifierKey, one of whose commitments is checked against the CPU
+    port; a flipped evaluation is rejected."""
+    import zkt_plonk_amd as z
+    cv = F.CURVES[cvname]
+    ctx = ctxs[cv.name]
+    n = 1 << log_n
+    tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
+    evals, w, vk = _bench_workload(z, ctx, cv, log_n, tau)
     srs = ctx.srs_download(0, n)
     coeffs = K.ntt_mont(cv, log_n, True, False, evals["q_c"])
     want, winf = K.msm_mont(cv, srs, coeffs)
-    assert not winf and np.array_equal(commits["q_c"][0], want)
-    gates = circ["gates"]
-    pi_pos = sorted(circ["pi"])
-    blinders = field_elems(cv.fr.p, 2020, P.NUM_BLINDERS)
-    tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * L)
-    z.seed_transcript(tr, n, pts)
-    proof = ctx.prove(K.fr_to_mont(cv, circ["a"][:gates]), K.fr_to_mont(cv, circ["b"][:gates]),
-                      K.fr_to_mont(cv, circ["c"][:gates]), K.fr_to_mont(cv, circ["table"]), pi_pos,
-                      K.fr_to_mont(cv, [circ["pi"][k] for k in pi_pos]), K.fr_to_mont(cv, blinders), tr)
-    assert len(proof) == (802 if cv.name == "bn254" else 1010)
-    dom = P.Domain(cv.fr, n)
-    w = dom.group_gen
-    vk = P.VerifierKey(n, [pow(w, i, cv.fr.p) for i in pi_pos], pts)
-    pis = [circ["pi"][k] for k in pi_pos]
+    assert not winf and K.points_from_mont(cv, want)[0] == vk.commits["q_c"]
+    del srs, coeffs, evals
+    proof = _gpu_prove_arrays(z, ctx, cv, w, vk, field_elems(cv.fr.p, 2020, P.NUM_BLINDERS))
+    assert len(proof) == 1010
+    pis = [w["pi"][k] for k in w["pi_pos"]]
     assert P.verify(cv, tau, vk, P.proof_deserialize(cv, proof), P.new_seeded_transcript(cv, vk), pis)
     bad = bytearray(proof)
     bad[-40] ^= 1                                   # inside the last evaluation (h2_eval)
     assert not P.verify(cv, tau, vk, P.proof_deserialize(cv, bytes(bad)), P.new_seeded_transcript(cv, vk), pis)
+    # free the 2^22 circuit (tens of GiB of HBM) before the next test loads its own
+    ctx.srs_generate(tau, 64)
+    z.GpuProver(ctx, 3, {k: np.zeros((0, 4), dtype=np.uint64) for k in z.PK_ORDER})
 
 
 def test_chained_proofs_with_prefetch(ctxs):
@@ -258,6 +300,160 @@ def test_chained_proofs_with_prefetch(ctxs):
     assert ctx.prove_prepared(preps[3], tr()) == want[3]
     for d in wires:
         ctx.free(d)
+
+
+def test_chained_proofs_with_distinct_witnesses_tables_and_public_inputs(ctxs):
+    """The alternate work set of zkt_prove_set_next (prover.hip swap_work_sets): proofs i and i+1 differ in everything a
+    prover is handed per proof -- wire values, lookup table (so the early round 2 rebuilds the table polynomial while
+    proof i still opens its own), public inputs, blinders -- and arrive in all three input forms (device wires, host
+    wires, the composer's variables + index vectors, whose host staging borrows the quotient vector and the round-5
+    work buffer).  Every proof must equal the oracle's bytes whether announced, unannounced or announced and dropped."""
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    css = [P.synthetic_circuit(cv, 900, 64, seed=78, value_seed=100 + k) for k in range(4)]
+    css.append(css[1])                       # same table as proof 1 but reached from a different one
+    cs0 = css[0]
+    n = cs0.circuit_bound()
+    tau = 0xC4A2
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs0, True)
+    for cs in css[1:]:
+        assert cs.check_satisfied() and P.setup_evals(be, cs) == P.setup_evals(be, cs0)   # one circuit, many witnesses
+        assert cs.table != cs0.table or cs is css[0]
+    assert len({tuple(sorted(cs.pi.items())) for cs in css[:4]}) == 4
+    ctx.srs_load(srs_arr)
+    z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+    bl = [field_elems(cv.fr.p, 700 + i, P.NUM_BLINDERS) for i in range(len(css))]
+    want = [P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), x).serialize(cv)
+            for cs, x in zip(css, bl)]
+    assert len(set(want)) == len(want)
+    to_idx = lambda ws: np.array([0xFFFFFFFF if v == P.ZERO_VAR else v for v in ws], dtype=np.uint32)
+    dev_bufs = []
+    preps = []
+    for k, (cs, x) in enumerate(zip(css, bl)):
+        pi_pos = sorted(cs.pi)
+        pi_vals = K.fr_to_mont(cv, [cs.pi[i] for i in pi_pos])
+        table = K.fr_to_mont(cv, cs.table)
+        blm = K.fr_to_mont(cv, x)
+        a, b, c = (K.fr_to_mont(cv, w) for w in cs.wire_evals(cs.n_gates))
+        if k % 3 == 0:       # witness resident in HBM
+            ds = []
+            for arr in (a, b, c):
+                d = ctx.alloc(arr.nbytes)
+                ctx.upload(d, arr)
+                ds.append(d)
+            dev_bufs += ds
+            preps.append(ctx.prepare_dev(ds[0], ds[1], ds[2], cs.n_gates, table, pi_pos, pi_vals, blm))
+        elif k % 3 == 1:     # host wire vectors
+            preps.append(ctx.prepare_host(a, b, c, table, pi_pos, pi_vals, blm))
+        else:                # the composer's layout, staged through the quotient vector
+            preps.append(ctx.prepare_vars(K.fr_to_mont(cv, cs.values), to_idx(cs.w_l), to_idx(cs.w_r), to_idx(cs.w_o),
+                                          table, pi_pos, pi_vals, blm))
+
+    def tr():
+        t = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+        return z.seed_transcript(t, vk.n, vk.commits)
+
+    # honoured announcements across all input forms and changing tables: 0 -> 1 -> 2 -> 3 -> 4(table of 1) -> 0
+    order = [0, 1, 2, 3, 4, 0]
+    for i, k in enumerate(order):
+        nxt = preps[order[i + 1]] if i + 1 < len(order) else None
+        assert ctx.prove_prepared(preps[k], tr(), nxt) == want[k], (i, k)
+    # announced and dropped: 1 announces 2, but 3 arrives; then unannounced proofs in reverse order
+    assert ctx.prove_prepared(preps[1], tr(), preps[2]) == want[1]
+    assert ctx.prove_prepared(preps[3], tr(), preps[0]) == want[3]
+    for k in (2, 1, 0):
+        assert ctx.prove_prepared(preps[k], tr()) == want[k], k
+    for d in dev_bufs:
+        ctx.free(d)
+
+
+def test_failed_proof_withdraws_the_announcement(ctxs):
+    """A proof that fails (a looked-up value outside the table) must leave no announcement armed: the successor's
+    buffers may be gone by the next call.  The next plain proof equals the oracle's bytes."""
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 300, 32, seed=91, value_seed=1)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, 0xFA11, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    ctx.srs_load(srs_arr)
+    z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+    blinders = field_elems(cv.fr.p, 3, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    pi_pos = sorted(cs.pi)
+    pi_vals = K.fr_to_mont(cv, [cs.pi[i] for i in pi_pos])
+    a, b, c = (K.fr_to_mont(cv, w) for w in cs.wire_evals(cs.n_gates))
+    good = ctx.prepare_host(a, b, c, K.fr_to_mont(cv, cs.table), pi_pos, pi_vals, K.fr_to_mont(cv, blinders))
+    row = next(i for i, q in enumerate(cs.q_lookup) if q)
+    cbad = c.copy()
+    cbad[row] = K.fr_to_mont(cv, [(cs.value_of(cs.w_o[row]) + 1) % cv.fr.p])[0]
+    bad = ctx.prepare_host(a, b, cbad, K.fr_to_mont(cv, cs.table), pi_pos, pi_vals, K.fr_to_mont(cv, blinders))
+    # the announced successor lives in arrays that are released right after the failure
+    doomed = ctx.prepare_host(a.copy(), b.copy(), c.copy(), K.fr_to_mont(cv, cs.table), pi_pos, pi_vals.copy(),
+                              K.fr_to_mont(cv, blinders))
+
+    def tr():
+        t = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+        return z.seed_transcript(t, vk.n, vk.commits)
+
+    import ctypes
+    L = z.lib()
+
+    def raw_prove(prep):   # zkt_prove alone: no zkt_prove_set_next call that would overwrite a stale announcement
+        t = tr()
+        out = (ctypes.c_uint8 * 2048)()
+        ln = ctypes.c_size_t(0)
+        rc = L.zkt_prove(ctx.handle, ctypes.byref(prep.struct), t.handle, out, 2048, ctypes.byref(ln))
+        return rc, bytes(out[:ln.value])
+
+    ctx.check(L.zkt_prove_set_next(ctx.handle, ctypes.byref(doomed.struct)))
+    rc, _ = raw_prove(bad)
+    assert rc == 8
+    for arr in doomed._keep:
+        if isinstance(arr, np.ndarray):
+            arr[...] = 0xDEADBEEF            # whoever still reads these produces garbage
+    ctx.profile_enable(True)
+    for rep in range(2):
+        before = ctx.profile_get("msm_main")[0]
+        rc, got = raw_prove(good)
+        assert rc == 0 and got == want
+        # 13 MSMs (12 once the table commitment is cached); early rounds of a stale successor would add 3 to 6
+        assert ctx.profile_get("msm_main")[0] - before <= 13, rep
+    ctx.profile_enable(False)
+    del doomed
+
+
+def test_srs_reload_invalidates_the_cached_table_commitment(ctxs):
+    """circuit_load -> prove -> srs_load(another key) -> prove(same table): the table polynomial's cached commitment
+    belongs to the first key and must not reach the second proof (the circuit state itself is SRS independent)."""
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 250, 32, seed=23)
+    n = cs.circuit_bound()
+    a, b, c = cs.wire_evals(cs.n_gates)
+    pi = {pos: K.fr_to_mont(cv, [v])[0] for pos, v in cs.pi.items()}
+    blinders = field_elems(cv.fr.p, 8, P.NUM_BLINDERS)
+    loaded = False
+    for tau in (1111, 2222, 1111):
+        srs_arr = K.srs_mont(cv, tau, n + 8)
+        be = K.CBackend(cv, srs_arr)
+        pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+        want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+        ctx.srs_load(srs_arr)
+        if not loaded:      # the circuit is loaded ONCE; only the key changes afterwards
+            prover = z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) for k in z.PK_ORDER})
+            loaded = True
+        for _ in range(2):  # second proof under each key takes the cached-table path
+            tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)
+            got = prover.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
+                               pi, K.fr_to_mont(cv, blinders), tr)
+            assert got == want, tau
 
 
 def test_repeated_proofs_reuse_the_table_polynomial(ctxs):

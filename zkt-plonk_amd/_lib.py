@@ -359,24 +359,48 @@ class Context:
         self.check(self._L.zkt_circuit_setup(self._h, log_n, ptrs, lens, 0, u64p(out), inf))
         return out, np.array([bool(x) for x in inf])
 
-    def prepare_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders) -> "PreparedInputs":
-        """zkt_prove_inputs for wire vectors already resident in HBM (device pointers), built once and reusable: the
-        prefetch of zkt_prove_set_next recognises the next proof by the identity of these pointers."""
+    def _prepare(self, wires, n_rows, table, pi_pos, pi_vals, blinders, on_device, variables=None, idx=None, keep=()):
         table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
         pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
         blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
         pos = (ctypes.c_size_t * max(1, len(pi_pos)))(*pi_pos)
         null = ctypes.POINTER(ctypes.c_uint64)()
+        null32 = ctypes.POINTER(ctypes.c_uint32)()
+        inp = ProveInputs(wires[0], wires[1], wires[2], n_rows, u64p(table) if table.size else null, table.shape[0],
+                          pos, u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), int(on_device),
+                          variables[0] if variables else null, variables[1] if variables else 0,
+                          idx[0] if idx else null32, idx[1] if idx else null32, idx[2] if idx else null32)
+        return PreparedInputs(inp, (table, pi_vals, blinders, pos) + tuple(keep))
+
+    def prepare_dev(self, d_a: int, d_b: int, d_c: int, n_rows: int, table, pi_pos, pi_vals, blinders) -> "PreparedInputs":
+        """zkt_prove_inputs for wire vectors already resident in HBM (device pointers), built once and reusable: the
+        prefetch of zkt_prove_set_next recognises the next proof by the identity of these pointers."""
         cast = lambda p: ctypes.cast(ctypes.c_void_p(p), ctypes.POINTER(ctypes.c_uint64))
-        inp = ProveInputs(cast(d_a), cast(d_b), cast(d_c), n_rows, u64p(table) if table.size else null, table.shape[0],
-                          pos, u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 1)
-        return PreparedInputs(inp, (table, pi_vals, blinders, pos))
+        return self._prepare((cast(d_a), cast(d_b), cast(d_c)), n_rows, table, pi_pos, pi_vals, blinders, True)
+
+    def prepare_host(self, a, b, c, table, pi_pos, pi_vals, blinders) -> "PreparedInputs":
+        """zkt_prove_inputs for wire vectors in host memory ((n_rows, 4) Montgomery uint64 arrays, kept alive here)."""
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c))
+        null = ctypes.POINTER(ctypes.c_uint64)()
+        return self._prepare(tuple(u64p(x) if x.size else null for x in (a, b, c)), a.shape[0], table, pi_pos, pi_vals,
+                             blinders, False, keep=(a, b, c))
+
+    def prepare_vars(self, variables, w_l, w_r, w_o, table, pi_pos, pi_vals, blinders) -> "PreparedInputs":
+        """zkt_prove_inputs in the composer's own witness layout (host memory): `variables` (n_vars, 4) Montgomery
+        values and three uint32 index vectors (0xFFFFFFFF = Variable::Zero); prove.rs:49-55 runs on the device."""
+        variables = np.ascontiguousarray(variables, dtype=np.uint64).reshape(-1, 4)
+        idx = [np.ascontiguousarray(w, dtype=np.uint32).reshape(-1) for w in (w_l, w_r, w_o)]
+        assert idx[0].shape == idx[1].shape == idx[2].shape
+        null = ctypes.POINTER(ctypes.c_uint64)()
+        u32p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        return self._prepare((null, null, null), idx[0].shape[0], table, pi_pos, pi_vals, blinders, False,
+                             variables=(u64p(variables) if variables.size else null, variables.shape[0]),
+                             idx=[u32p(x) for x in idx], keep=(variables, idx))
 
     def prove_prepared(self, prep: "PreparedInputs", transcript, next_prep: "PreparedInputs" = None) -> bytes:
         """zkt_prove on prepared inputs.  next_prep announces the proof that follows (zkt_prove_set_next): its
         challenge-free rounds 1 and 2 are issued behind this proof's last commitments."""
-        if next_prep is not None:
-            self.check(self._L.zkt_prove_set_next(self._h, ctypes.byref(next_prep.struct)))
+        self.check(self._L.zkt_prove_set_next(self._h, ctypes.byref(next_prep.struct) if next_prep is not None else None))
         out = (ctypes.c_uint8 * 2048)()
         n = ctypes.c_size_t(0)
         self.check(self._L.zkt_prove(self._h, ctypes.byref(prep.struct), transcript.handle, out, 2048, ctypes.byref(n)))
@@ -388,40 +412,11 @@ class Context:
 
     def prove(self, a, b, c, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
         """proof_system::prove (prove.rs:59-470); all arrays are (len, 4) Montgomery uint64."""
-        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c))
-        table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
-        pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
-        blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
-        pos = (ctypes.c_size_t * max(1, len(pi_pos)))(*pi_pos)
-        null = ctypes.POINTER(ctypes.c_uint64)()
-        inp = ProveInputs(u64p(a) if a.size else null, u64p(b) if b.size else null, u64p(c) if c.size else null,
-                          a.shape[0], u64p(table) if table.size else null, table.shape[0], pos,
-                          u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 0)
-        out = (ctypes.c_uint8 * 2048)()
-        n = ctypes.c_size_t(0)
-        self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))
-        return bytes(out[:n.value])
+        return self.prove_prepared(self.prepare_host(a, b, c, table, pi_pos, pi_vals, blinders), transcript)
 
     def prove_vars(self, variables, w_l, w_r, w_o, table, pi_pos, pi_vals, blinders, transcript) -> bytes:
-        """proof_system::prove from the composer's own witness layout: `variables` (n_vars, 4) Montgomery values and
-        three uint32 index vectors (0xFFFFFFFF = Variable::Zero); prove.rs:49-55 wire_evals runs on the device."""
-        variables = np.ascontiguousarray(variables, dtype=np.uint64).reshape(-1, 4)
-        idx = [np.ascontiguousarray(w, dtype=np.uint32).reshape(-1) for w in (w_l, w_r, w_o)]
-        assert idx[0].shape == idx[1].shape == idx[2].shape
-        table = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
-        pi_vals = np.ascontiguousarray(pi_vals, dtype=np.uint64).reshape(-1, 4)
-        blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(19, 4)
-        pos = (ctypes.c_size_t * max(1, len(pi_pos)))(*pi_pos)
-        null = ctypes.POINTER(ctypes.c_uint64)()
-        u32p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
-        inp = ProveInputs(null, null, null, idx[0].shape[0], u64p(table) if table.size else null, table.shape[0], pos,
-                          u64p(pi_vals) if pi_vals.size else null, len(pi_pos), u64p(blinders), 0,
-                          u64p(variables) if variables.size else null, variables.shape[0], u32p(idx[0]), u32p(idx[1]),
-                          u32p(idx[2]))
-        out = (ctypes.c_uint8 * 2048)()
-        n = ctypes.c_size_t(0)
-        self.check(self._L.zkt_prove(self._h, ctypes.byref(inp), transcript.handle, out, 2048, ctypes.byref(n)))
-        return bytes(out[:n.value])
+        """proof_system::prove from the composer's own witness layout (see prepare_vars)."""
+        return self.prove_prepared(self.prepare_vars(variables, w_l, w_r, w_o, table, pi_pos, pi_vals, blinders), transcript)
 
     # -- debug hooks ----------------------------------------------------------------------------------
     def debug_params(self, which: int):

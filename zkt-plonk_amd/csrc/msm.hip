@@ -753,6 +753,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     }
     c->msm = st;
     ++c->msm_epoch;
+    ++c->srs_generation;
     return ZKT_OK;
 }
 

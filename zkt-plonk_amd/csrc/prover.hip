@@ -71,6 +71,7 @@ struct CircuitState {
     // evaluations, coefficients, 4n-coset and commitment are reused (one MSM and two transforms less).
     std::vector<uint64_t> cached_table;
     bool t_cached = false, t_coset_valid = false;
+    uint64_t t_srs_generation = 0;   // zkt_ctx::srs_generation the cached commitment was made under
     uint64_t t_commit_xy[12] = {};
 };
 
@@ -368,7 +369,10 @@ struct Prover {
     int enqueue_round_2(const zkt_prove_inputs& in, bool* same_table_out) {
         const size_t n = S.n;
         int rc;
-        const bool same_table = S.t_cached && S.cached_table.size() == 4 * in.table_len &&
+        // the cached commitment belongs to the SRS it was made under: a reloaded key invalidates it (the polynomial and
+        // its coset would survive, but one flag keeps the three together)
+        const bool same_table = S.t_cached && S.t_srs_generation == c->srs_generation &&
+                                S.cached_table.size() == 4 * in.table_len &&
                                 (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
         *same_table_out = same_table;
         if (!same_table) {
@@ -427,6 +431,7 @@ struct Prover {
             memcpy(S.t_commit_xy + Q::N / 2, cm[3].y.v, Q::N * 4);
             S.cached_table.assign(in.table, in.table + 4 * in.table_len);
             S.t_cached = true;
+            S.t_srs_generation = c->srs_generation;
         } else {
             memcpy(cm[3].x.v, S.t_commit_xy, Q::N * 4);
             memcpy(cm[3].y.v, S.t_commit_xy + Q::N / 2, Q::N * 4);
@@ -977,7 +982,13 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
         rc = p.run(*in, proof);
         if (rc) (void)hipStreamSynchronize(c->stream);
     }
-    if (rc) return rc;
+    if (rc) {
+        // a failed proof withdraws the announcement of its successor: the next call must not issue early work from
+        // pointers the caller may have released meanwhile, nor pick up half-issued early rounds
+        c->circuit->has_next = false;
+        c->circuit->prefetch_stage = 0;
+        return rc;
+    }
     if (len) *len = proof.size();
     if (proof.size() > cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "proof buffer too small");
     memcpy(out, proof.data(), proof.size());
