@@ -2,17 +2,26 @@
 """bench.py -- proofs/sec of the MI355X prover hot path on a synthetic withdraw-shaped circuit.
 
 A "step" is one full pass of proof_system::prove (plonk-core/src/proof_system/prove.rs:59-470) over one
-batch of synthetic witness rows already resident in HBM: 9 iNTT(n), 10 NTT(4n), the fused quotient
-pass, two grand products, 13 KZG MSMs of ~n points, the 12 evaluations and the two openings, with
-Fiat-Shamir (Merlin) on the host.  Default workload: BASELINE.json configs[3] shape -- BN254,
-n = 2^20 rows, TABLE_SIZE = 1024, 7 public inputs.
+batch of synthetic witness rows already resident in HBM: iNTT(n) of every witness polynomial, their
+coset NTT(4n), the fused quotient pass, two grand products, the KZG commitments (MSMs of ~n points),
+the 12 evaluations and the two openings, with Fiat-Shamir (Merlin) on the host.  Default workload:
+BASELINE.json configs[3] shape -- BN254, n = 2^20 rows, TABLE_SIZE = 1024, 7 public inputs.
 
-With N > 1 (one process per GPU, launched by torch.distributed.run) independent proofs are sharded
-across the ranks (no data-path collective): scaling = "weak".
+Headline (`value`): steady state of a proving service with a queue -- two DISTINCT witnesses of the circuit
+alternate, each proof announces its successor (zkt_prove_set_next), witnesses resident in HBM, the lookup
+table (part of the circuit) unchanged, so its polynomial / commitment / coset are reused.  `config` says so,
+and `latency` reports the other end in the same line: a cold single proof (host witness pointers crossing
+PCIe, fresh table, no announcement).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the MSM bucket accumulation),
-measured live with HIP events on the stream the kernel runs on; `cpu_baseline` times the CPU oracle
-(a port, oracle/coracle.cpp) on a bounded sample of the same workload on this box's host cores.
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N worker processes itself through
+torch.distributed.run BEFORE anything touches a GPU; under the driver's own torch.distributed.run launch the
+workers are already there.  One process per GPU, independent proofs sharded across ranks, no data-path
+collective: "scaling": "weak".
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the MSM bucket accumulation), timed
+live with HIP events on the stream the kernel runs on; `cpu_baseline` times ONE full proof of the same
+workload by the CPU oracle (oracle/fastplonk.py + oracle/coracle.cpp: a port, OpenMP over the host cores)
+and checks that its bytes equal the GPU proof's.
 """
 import argparse
 import json
@@ -57,12 +66,16 @@ def fr_to_mont_gpu(ctx, fld, vals):
     return ctx.debug_fr_mul(arr, r2arr)
 
 
-def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED):
+def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED, value_seed=None):
     """Withdraw-shaped synthetic trace of exactly 2^log_n rows: mul / add / linear
     gates chained through copy constraints (output of row i-1 = left input of row i), a lookup row every 16,
-    n_public public-input rows.  Pure Python integers; no reference or oracle code involved."""
+    n_public public-input rows.  Pure Python integers; no reference or oracle code involved.
+    `seed` fixes the circuit (selectors, permutation, lookup table); `value_seed` draws the witness (free wire
+    values, looked-up entries, public inputs) from its own generator, so that several witnesses of ONE circuit
+    can be produced (None: one generator for both, the round-1 workload)."""
     import random
     rnd = random.Random(seed)
+    vr = rnd if value_seed is None else random.Random(value_seed)
     p = fld["r"]
     n = 1 << log_n
     gates = n - 8
@@ -85,20 +98,21 @@ def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED):
     pi = {}
     prev_out = None  # row whose output wire is copied into this row's left wire
     rr = rnd.randrange
+    vrr = vr.randrange
     for i in range(gates - n_public):
         if i % 16 == 15:
-            t = table[rr(len(table))]
+            t = table[vrr(len(table))]
             a[i] = t; c[i] = t
             q_l[i] = 1; q_o[i] = p - 1; q_lk[i] = 1
         else:
             if prev_out is None:
-                a[i] = rr(p)
+                a[i] = vrr(p)
             else:
                 a[i] = c[prev_out]
                 # one permutation cycle {Output(prev_out), Left(i)}
                 s3[prev_out] = roots[i]
                 s1[i] = K2 * roots[prev_out] % p
-            b[i] = rr(p)
+            b[i] = vrr(p)
             k = i % 3
             if k == 0:
                 c[i] = a[i] * b[i] % p
@@ -112,7 +126,7 @@ def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED):
                 q_l[i] = ql; q_r[i] = qr; q_o[i] = p - 1; q_c[i] = qc
         prev_out = i
     for i in range(gates - n_public, gates):
-        v = rr(p)
+        v = vrr(p)
         c[i] = v
         q_o[i] = p - 1
         pi[i] = v
@@ -120,6 +134,21 @@ def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED):
     sel = dict(q_m=q_m, q_l=q_l, q_r=q_r, q_o=q_o, q_c=q_c, sigma1=s1, sigma2=s2, sigma3=s3, q_lookup=q_lk,
                q_table=q_table)
     return dict(n=n, gates=gates, a=a, b=b, c=c, sel=sel, table=table, pi=pi)
+
+
+def launch_workers(args, argv):
+    """`--gpus N` without a torchrun environment: start the N workers ourselves, as child processes, before this
+    process has touched a GPU (it never does: no torch / HIP call happens on this path)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -130,7 +159,10 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--curve", default="bn254", choices=sorted(FIELDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the cold / unchained single-proof legs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args, sys.argv[1:]))
 
     import torch
     import zkt_plonk_amd as z
@@ -159,14 +191,19 @@ def main():
     t0 = time.time()
     ctx = z.Context(args.curve, dev.index)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    ctx.srs_generate(0x5EED5EED1234567890ABCDEF % fld["r"], n + 8)
+    tau = 0x5EED5EED1234567890ABCDEF % fld["r"]
+    ctx.srs_generate(tau, n + 8)
 
-    circ = synthetic_circuit(fld, log_n)
+    # ONE circuit, TWO witnesses (free wire values, looked-up entries and public inputs all differ)
+    circs = [synthetic_circuit(fld, log_n, value_seed=1 + k) for k in range(2)]
+    assert circs[0]["sel"] == circs[1]["sel"] and circs[0]["table"] == circs[1]["table"] and circs[0]["pi"] != circs[1]["pi"]
     # proof_system::setup on the device (setup.rs:42-166): selector / sigma / table-mask evaluations -> ProverKey,
     # ExtendedProverKey and the ten VerifierKey commitments that seed the transcript
-    evals = {name: fr_to_mont_gpu(ctx, fld, circ["sel"][name]) for name in z.PK_ORDER}
+    evals = {name: fr_to_mont_gpu(ctx, fld, circs[0]["sel"][name]) for name in z.PK_ORDER}
     prover, commits = z.GpuProver.setup(ctx, log_n, evals)
-    del evals
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not want_cpu:
+        del evals
     L = fld["fq_limbs"]
     rinv_q = pow(1 << (64 * L), -1, fld["q"])
     vk = {}
@@ -178,27 +215,38 @@ def main():
             x = sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv_q % fld["q"]
             y = sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv_q % fld["q"]
             vk[name] = (x, y)
-    gates = circ["gates"]
-    wires = [torch.from_numpy(fr_to_mont_gpu(ctx, fld, circ[k][:gates]).view(np.int64)).to(dev) for k in "abc"]
-    table = fr_to_mont_gpu(ctx, fld, circ["table"])
-    pi_pos = sorted(circ["pi"])
-    pi_vals = fr_to_mont_gpu(ctx, fld, [circ["pi"][k] for k in pi_pos])
+    gates = circs[0]["gates"]
+    table = fr_to_mont_gpu(ctx, fld, circs[0]["table"])
     import random
     rnd = random.Random(99)
-    blinders = fr_to_mont_gpu(ctx, fld, [rnd.randrange(fld["r"]) for _ in range(z.NUM_BLINDERS)])
-    del circ
+    host_w, dev_w, preps, pis = [], [], [], []
+    for circ in circs:
+        hw = [fr_to_mont_gpu(ctx, fld, circ[k][:gates]) for k in "abc"]
+        dw = [torch.from_numpy(x.view(np.int64)).to(dev) for x in hw]
+        pi_pos = sorted(circ["pi"])
+        pi_vals = fr_to_mont_gpu(ctx, fld, [circ["pi"][k] for k in pi_pos])
+        blinders = fr_to_mont_gpu(ctx, fld, [rnd.randrange(fld["r"]) for _ in range(z.NUM_BLINDERS)])
+        host_w.append(hw); dev_w.append(dw); pis.append((pi_pos, pi_vals, blinders))
+        preps.append(ctx.prepare_dev(dw[0].data_ptr(), dw[1].data_ptr(), dw[2].data_ptr(), gates, table, pi_pos, pi_vals,
+                                     blinders))
+    pi_map0 = dict(circs[0]["pi"])
+    del circs
     setup_s = time.time() - t0
 
-    # The same witness is proved over and over; every proof announces the next one (zkt_prove_set_next), as a proving
+    # Timed regime: the two witnesses alternate; every proof announces the next one (zkt_prove_set_next), as a proving
     # service with a queue would: rounds 1 and 2 of proof i+1 are issued behind the last commitments of proof i.
-    prep = ctx.prepare_dev(wires[0].data_ptr(), wires[1].data_ptr(), wires[2].data_ptr(), gates, table, pi_pos, pi_vals,
-                           blinders)
     chain = os.environ.get("ZKT_BENCH_NO_CHAIN") is None
 
-    def one_proof():
+    def transcript():
         tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=fld["lam"], fq_bytes=8 * L)
-        z.seed_transcript(tr, n, vk)                                # plonk.rs:105-106
-        return ctx.prove_prepared(prep, tr, prep if chain else None)
+        return z.seed_transcript(tr, n, vk)                                # plonk.rs:105-106
+
+    count = [0]
+
+    def one_proof():
+        k = count[0] & 1
+        count[0] += 1
+        return ctx.prove_prepared(preps[k], transcript(), preps[k ^ 1] if chain else None)
 
     from zkt_plonk_amd import parallel as par
 
@@ -228,6 +276,42 @@ def main():
     value = total_proofs / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # ---- the other end of the range, same line: single proofs nobody announced -------------------------------------
+    latency = None
+    if rank == 0 and not args.no_latency:
+        ctx.prove_prepared(preps[0], transcript())      # drains the last announcement
+
+        def timed(fn, reps=3):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(dev)
+                ts.append(1e3 * (time.perf_counter() - t))
+            return ts
+
+        warm = timed(lambda: ctx.prove_prepared(preps[0], transcript()))
+        # cold: witness in HOST memory (crosses PCIe inside the call), the lookup table handed over in a different
+        # order each time (same set: nothing of the table polynomial can be reused), no announcement
+        tswap = table.copy()
+        tswap[[0, 1]] = tswap[[1, 0]]
+        tabs = [tswap, table]
+        k = [0]
+
+        def cold():
+            pi_pos, pi_vals, blinders = pis[0]
+            hw = host_w[0]
+            ctx.prove(hw[0], hw[1], hw[2], tabs[k[0] & 1], pi_pos, pi_vals, blinders, transcript())
+            k[0] += 1
+
+        cold_ts = timed(cold)
+        latency = {"cold_single_proof_ms": round(min(cold_ts), 3),
+                   "cold_is": "host witness pointers (3 x %d MiB over PCIe inside the call), fresh lookup table, no announcement; "
+                              "min of 3" % (gates * 32 >> 20),
+                   "unchained_single_proof_ms": round(min(warm), 3),
+                   "unchained_is": "witness in HBM, table cached, no announcement; min of 3"}
+
     # ---- roofline of the dominant kernel (MSM bucket accumulation), live HIP-event timing ----
     acc_calls, acc_ms = prof["msm_accumulate"]
     msm_points = n + 3                                              # typical MSM length of the prover
@@ -248,11 +332,15 @@ def main():
     Lq = -(-32 * 2 * L // 29)                                      # 9 (BN254 Fq), 14 (BLS12-381 Fq)
     mads_per_add = 6 * 2 * Lq * Lq + 2 * (Lq * (Lq + 1) // 2 + Lq * Lq) + 3 * Lq * Lq
     mad_ceiling = N_SIMD * 64 * CLOCK_HZ / MAD_CYCLES               # v_mad_u64_u32 issue ceiling, lanes/s
+    traffic, traffic_src = pmc_traffic("k_msm_accumulate", args.curve, log_n)
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_acc_s * 1e3, 4), "launches": acc_calls,
-        "note": "integer-ALU bound (v_mad_u64_u32 issue), not HBM bound: see int_alu",
+        "frac_of_mad_issue_ceiling": round(mads_per_add * mixed_adds / avg_acc_s / mad_ceiling, 4) if avg_acc_s > 0 else None,
+        "note": "integer-ALU bound (v_mad_u64_u32 issue), not HBM bound: the contract's HBM fraction is reported, the "
+                "binding ceiling is frac_of_mad_issue_ceiling (see int_alu); traffic = measured gather traffic of W*n "
+                "random table points, not re-reads",
     }
     int_alu = {
         "msm_g1_adds_per_s_reference_formula": round(ref_adds / avg_msm_s, 1) if avg_msm_s > 0 else None,
@@ -264,14 +352,21 @@ def main():
         "msm_avg_ms": round(avg_msm_s * 1e3, 4), "msm_launches": msm_calls,
         "msm_tail_avg_ms": round(tail_ms / max(tail_calls, 1), 4),
     }
+    # NTT: HBM fraction (the BASELINE metric) and the fraction of the mad ceiling.  Products per transform: one twiddle
+    # product per butterfly output that has a non-unit twiddle, (N/2) log2 N at most; L^2-term schoolbook + reduction
+    # = 2 L^2 + L multiply-adds each on L = 9 limbs.
+    Lr = 9
+    mads_per_mul = 2 * Lr * Lr + Lr
     ntt = {}
     for lg in (log_n, log_n + 2):
         calls, ms = prof["ntt_%d" % lg]
         if calls:
             avg = ms / calls * 1e-3
+            muls = (1 << lg) // 2 * lg
             ntt["ntt_2^%d" % lg] = {"avg_ms": round(avg * 1e3, 4), "launches": calls,
                                     "GB/s": round(64.0 * (1 << lg) / avg / 1e9, 2),
-                                    "frac_hbm": round(64.0 * (1 << lg) / avg / 1e9 / HBM_PEAK_GBS, 5)}
+                                    "frac_hbm": round(64.0 * (1 << lg) / avg / 1e9 / HBM_PEAK_GBS, 5),
+                                    "frac_of_mad_issue_ceiling_upper": round(muls * mads_per_mul / avg / mad_ceiling, 4)}
     qc, qms = prof["quotient"]
     if qc:
         qavg = qms / qc * 1e-3
@@ -285,13 +380,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": "full prove, synthetic withdraw-shaped circuit, %s, n=2^%d, TABLE_SIZE=1024, 7 public inputs"
                                % (args.curve, log_n), "parallelism": "proofs sharded across %d GPU(s)" % world,
-                   "chained": bool(chain),
+                   "chained": bool(chain), "distinct_witnesses": 2, "witness_on_device": True, "table_cached": True,
                    "proof_bytes": len(proof), "setup_s": round(setup_s, 1)},
         "roofline": roofline, "int_alu": int_alu, "kernels": ntt,
     }
+    if latency is not None:
+        out["latency"] = latency
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ctx, args.curve, log_n)
+    if want_cpu:
+        pi_pos, pi_vals, blinders = pis[0]
+        gpu_proof = ctx.prove_prepared(preps[0], transcript())
+        out["cpu_baseline"] = cpu_baseline(ctx, args.curve, log_n, evals, host_w[0], table, pi_map0, blinders, vk, gpu_proof)
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
@@ -299,23 +398,51 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(ctx, curve, log_n):
-    """The CPU oracle (oracle/coracle.cpp: a port of ark-poly's radix-2 FFT and ark-ec's Pippenger, OpenMP
-    over the host cores) timed on one MSM(n), one iNTT(n) and one coset-NTT(4n); a proof is priced as
-    14 MSM + 9 iNTT(n) + 10 NTT(4n), the pointwise passes being left out."""
-    from oracle import coracle as K, fields as F
+def pmc_traffic(kernel, curve, log_n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
+    profiles/pmc_traffic_*.txt: FETCH_SIZE and WRITE_SIZE in separate runs, KiB per launch; on gfx950 FETCH_SIZE counts
+    64-B units for the 128-B requests of wide coalesced loads, MI355X_MICROARCH.md).  The accumulation kernel's reads are
+    scattered 64-B points, so its raw FETCH_SIZE is taken as is.  Only valid for the default workload."""
+    if curve != "bn254" or log_n != 20:
+        return None, None
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic_r*.txt"))):
+        for line in open(f):
+            if line.startswith(kernel):
+                parts = line.split()
+                try:
+                    fetch_kib, write_kib = float(parts[-2]), float(parts[-1])
+                except ValueError:
+                    continue
+                key = [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
+                if best is None or key >= best[0]:
+                    best = (key, (fetch_kib + write_kib) * 1024.0, os.path.basename(f))
+    if best is None:
+        return None, None
+    return round(best[1]), "profiles/" + best[2]
+
+
+def cpu_baseline(ctx, curve, log_n, evals, wires, table, pi, blinders, vk_pts, gpu_proof):
+    """ONE full proof of the same workload by the CPU oracle (oracle/fastplonk.py: the array twin of the restated
+    prove.rs:59-470, every O(n) loop in oracle/coracle.cpp -- a port of ark-poly's radix-2 FFT, ark-ec's Pippenger
+    and the prover's own loops, OpenMP over the host cores), timed, on the same SRS / witness / blinders; its bytes
+    must equal the GPU proof's.  Key preparation (ExtendedProverKey) is outside the timed region on both sides."""
+    from oracle import coracle as K, fields as F, fastplonk as FP, plonk as P
     cv = F.CURVES[curve]
     n = 1 << log_n
-    rng = np.random.default_rng(5)
-    sc = rng.integers(0, 1 << 61, size=(n, 4), dtype=np.uint64)
-    srs = ctx.srs_download(0, n)
-    t = time.perf_counter(); K.msm_mont(cv, srs, sc, True); t_msm = time.perf_counter() - t
-    t = time.perf_counter(); K.ntt_mont(cv, log_n, True, False, sc); t_intt = time.perf_counter() - t
-    t = time.perf_counter(); K.ntt_mont(cv, log_n + 2, False, True, sc); t_ntt4 = time.perf_counter() - t
-    per_proof = 14 * t_msm + 9 * t_intt + 10 * t_ntt4   # the reference's own counts (SURVEY.md section 3.2)
-    return {"value": round(1.0 / per_proof, 5), "unit": "proofs/s", "cores": K.num_threads(), "kind": "port",
-            "sample": "1 MSM(2^%d) %.2fs + 1 iNTT(2^%d) %.2fs + 1 coset-NTT(2^%d) %.2fs, scaled to 14/9/10 per proof"
-                      % (log_n, t_msm, log_n, t_intt, log_n + 2, t_ntt4)}
+    srs = ctx.srs_download(0, n + 8)
+    keys = FP.setup(cv, srs, log_n, evals, commitments=False)
+    keys.commits = dict(vk_pts)
+    vk = keys.verifier_key(cv, pi.keys())
+    bl = K.fr_from_mont(cv, blinders)
+    t = time.perf_counter()
+    cpu_proof = FP.prove(cv, srs, keys, wires[0], wires[1], wires[2], table, pi, P.new_seeded_transcript(cv, vk), bl)
+    dt = time.perf_counter() - t
+    return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": K.num_threads(), "kind": "port",
+            "sample": "1 full proof (n=2^%d, same SRS / witness / blinders as the GPU proof) in %.2f s" % (log_n, dt),
+            "proof_bytes_equal_gpu": cpu_proof == gpu_proof}
 
 
 if __name__ == "__main__":
