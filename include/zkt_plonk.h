@@ -49,7 +49,8 @@ enum {
     ZKT_ERR_EQUAL_CHALLENGES = 7,      /* reference: assert_ne! at prove.rs:202-207               */
     ZKT_ERR_NOT_IN_TABLE = 8,          /* Error::ElementNotIndexedInTable, multiset.rs:121        */
     ZKT_ERR_QUOTIENT_TOO_SHORT = 9,    /* reference: slice panic at prove.rs:287-300              */
-    ZKT_ERR_NOT_LOADED = 10
+    ZKT_ERR_NOT_LOADED = 10,
+    ZKT_ERR_COMM = 11                  /* the caller's communicator reported a failure */
 };
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -69,6 +70,39 @@ int zkt_profile_enable(zkt_ctx* ctx, int on);
 int zkt_profile_get(zkt_ctx* ctx, const char* name, uint64_t* calls, double* total_ms);
 const char* zkt_version(void);
 
+/* ---- one proof across the GPUs of a node (BASELINE.json configs[4]) -------------------------
+ * One process (and one context) per GPU; the same calls are made on every rank with the same inputs.  What shards:
+ *   - every KZG commitment (commitment.rs:24-46): rank r keeps the SRS slice zkt_shard_range(total, r, world) and sums
+ *     over it; the partial sums of a prover round travel in ONE all-gather as raw bytes (world x k x 128|192 B) and are
+ *     added on every rank (a collective cannot reduce curve points);
+ *   - the 4n-coset work of round 4 (quotient_poly.rs:52-224): rank r owns the coset points whose index is r modulo
+ *     world -- a coset of 4n / world points on which it transforms the nine witness polynomials (keys: once, at load)
+ *     and runs the fused quotient pass with no communication ("omega-next" = index + 4 stays in the class for world
+ *     <= 4; with 8 ranks the four shifted vectors are transformed on the neighbouring class as well).  ONE all-gather
+ *     of 4n x 32 B in total brings the quotient evaluations together before the inverse transform.
+ * Everything else (the n-point inverse transforms, grand products, evaluations, openings' polynomials, Fiat-Shamir) is
+ * replicated: every rank produces the same proof bytes, equal to the single-GPU bytes.
+ * The communicator is supplied by the caller (torch.distributed over RCCL in zkt-plonk_amd/parallel.py; any other
+ * transport in a Rust host).  all_gather: `bytes` per rank, results in rank order; on_device = 0: host pointers;
+ * on_device = 1 (only if device_buffers != 0): device pointers, the library has synchronised `hip_stream` before the
+ * call and the exchange must be complete when the callback returns.  Returns 0 on success. */
+typedef struct {
+    void* user;
+    int rank;
+    int world;               /* 1, 2, 4 or 8 */
+    int device_buffers;      /* 0: device exchanges are staged through pinned host memory by the library */
+    int (*all_gather)(void* user, const void* send, void* recv, size_t bytes, int on_device, void* hip_stream);
+} zkt_comm_vtable;
+/* Attach (or, with NULL / world = 1, detach) the communicator.  Must precede zkt_srs_load_slice / zkt_circuit_load /
+ * zkt_circuit_setup of the sharded proof: keys are laid out for the rank's share. */
+int zkt_ctx_set_comm(zkt_ctx* ctx, const zkt_comm_vtable* comm);
+/* Contiguous share [*lo, *hi) of `total` units for `rank` (sizes differ by at most one). */
+int zkt_shard_range(size_t total, int rank, int world, size_t* lo, size_t* hi);
+/* Exchanged bytes and collective calls since the communicator was attached (this rank's send side). */
+int zkt_comm_stats(zkt_ctx* ctx, uint64_t* calls, uint64_t* bytes_sent);
+/* Plumbing check without a GPU: gathers `bytes` from every rank through the vtable (host buffers). */
+int zkt_comm_selftest(const zkt_comm_vtable* comm, const void* send, void* recv, size_t bytes);
+
 /* ---- device memory helpers (plumbing for callers without their own allocator) -------------- */
 int zkt_dev_alloc(zkt_ctx* ctx, size_t bytes, void** dptr);
 int zkt_dev_free(zkt_ctx* ctx, void* dptr);
@@ -86,6 +120,11 @@ int zkt_dev_download(zkt_ctx* ctx, void* host, const void* dptr, size_t bytes);
  * in_len > 2^log_n -> ZKT_ERR_INVALID_DOMAIN_SIZE. */
 int zkt_ntt(zkt_ctx* ctx, int log_n, int inverse, int coset, const uint64_t* in, size_t in_len, uint64_t* out);
 int zkt_ntt_dev(zkt_ctx* ctx, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out);
+/* One GPU's share of D::coset_fft on the domain of size 2^log_big (util.rs:117-140) sharded by output index over
+ * G = 2^(log_big - log_n) GPUs: out[i] = p(g w_big^(cls + G i)), i < 2^log_n -- the evaluations whose index is cls
+ * modulo G, a coset of their own, obtained by one 2^log_n-point transform with no exchange.  in_len may exceed 2^log_n
+ * (the polynomial is folded modulo X^(2^log_n) - shift^(2^log_n) first).  Host pointers. */
+int zkt_ntt_class(zkt_ctx* ctx, int log_n, int log_big, int cls, const uint64_t* in, size_t in_len, uint64_t* out);
 /* EvaluationDomainExt::group_gen (util.rs:52-58): writes the 2^log_n-th root of unity (4 limbs). */
 int zkt_domain_group_gen(zkt_ctx* ctx, int log_n, uint64_t* out4);
 
@@ -100,6 +139,11 @@ int zkt_srs_load_dev(zkt_ctx* ctx, const void* d_g1_xy_mont, size_t count);
  * Stands in for PC::setup (ark-poly-commit kzg10 setup), which is out of scope; insecure by design. */
 int zkt_srs_generate(zkt_ctx* ctx, const uint64_t* tau_canonical4, size_t count);
 int zkt_srs_download(zkt_ctx* ctx, size_t offset, size_t count, uint64_t* out_xy_mont);
+/* Sharded committer key: this rank keeps powers [offset, offset + count) of a key of `total` powers -- its
+ * zkt_shard_range(total, rank, world).  The window table shrinks by the number of ranks.  zkt_msm_g1* then index into the
+ * slice; zkt_prove / zkt_circuit_setup combine the ranks' partial sums through the communicator. */
+int zkt_srs_load_slice(zkt_ctx* ctx, const uint64_t* g1_xy_mont_slice, size_t offset, size_t count, size_t total);
+int zkt_srs_generate_slice(zkt_ctx* ctx, const uint64_t* tau_canonical4, size_t offset, size_t count, size_t total);
 /* sum_i scalars[i] * powers_of_g[base_offset + i], affine result (x || y Montgomery limbs, (0,0) and
  * *out_is_infinity = 1 for the identity).  This is VariableBaseMSM::multi_scalar_mul as called by
  * kzg10::commit / open_with_witness_polynomial (prove.rs:133-135,178-180,249-251,306-308,373-375,

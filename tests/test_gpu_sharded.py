@@ -1,0 +1,191 @@
+"""One proof across several GPUs (BASELINE.json configs[4]) rehearsed on ONE GPU: the ranks are
+contexts of one process (threads, parallel.LocalGroup) or processes over gloo; every rank's proof bytes must equal the
+oracle's (= the single-GPU bytes).  The class transform the sharding rests on is pinned to the oracle on its own."""
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fields as F, plonk as P, coracle as K
+from helpers import field_elems, rand_fr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CURVES = [F.BN254, F.BLS12_381]
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_class_transform_is_the_decimated_coset_transform(cv):
+    """zkt_ntt_class: out[i] = p(g w_big^(cls + G i)) -- every class of every split of the coset transform, ragged and
+    over-long (folded) inputs, single-workgroup and multi-pass sizes."""
+    import zkt_plonk_amd as z
+    ctx = z.Context(cv.name, 0)
+    rng = np.random.default_rng(5)
+    for log_big, lens in ((7, (1, 40, 32 + 8)), (12, (1000, 1024 + 8)), (14, (4096 + 8,)), (18, (65536 + 8,))):
+        for in_len in lens:
+            x = rand_fr(rng, in_len)
+            full = K.ntt_mont(cv, log_big, False, True, x)
+            for lg in (1, 2, 3):
+                G = 1 << lg
+                classes = range(G) if log_big <= 14 else (0, G - 1)
+                for cls in classes:
+                    got = ctx.ntt_class(log_big - lg, log_big, cls, x)
+                    assert np.array_equal(got, full[cls::G]), (log_big, in_len, G, cls)
+    with pytest.raises(z.ZktError):
+        ctx.ntt_class(5, 7, 4, rand_fr(rng, 8))        # class index outside the split
+    ctx.close()
+
+
+def _setup_oracle(cv, cs, tau):
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    return n, srs_arr, be, pk, epk, vk
+
+
+def _rank_job(z, par, comm, cv, n, srs_arr, evals, vk, jobs, out, rank, world, use_setup):
+    """What one rank of a sharded prover does: its SRS slice, the circuit (laid out for its class), the proofs."""
+    try:
+        ctx = z.Context(cv.name, 0)
+        ctx.set_comm(comm)
+        lo, hi = par.shard_range(n + 8, rank, world)
+        ctx.srs_load_slice(srs_arr[lo:hi], lo, n + 8)
+        log_n = n.bit_length() - 1
+        if use_setup:
+            prover, commits = z.GpuProver.setup(ctx, log_n, evals["evals"])
+            L = cv.fq.limbs64
+            rinv = pow(1 << (64 * L), -1, cv.fq.p)
+            for name in z.PK_ORDER:
+                xy, inf = commits[name]
+                pt = None if inf else (sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % cv.fq.p,
+                                       sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % cv.fq.p)
+                assert pt == vk.commits[name], name
+        else:
+            z.GpuProver(ctx, log_n, evals["pk"])
+        proofs = []
+        preps = [ctx.prepare_host(*job) for job in jobs]
+        for i, prep in enumerate(preps):
+            tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+            z.seed_transcript(tr, vk.n, vk.commits)
+            proofs.append(ctx.prove_prepared(prep, tr, preps[i + 1] if i + 1 < len(preps) else None))
+        out[rank] = (proofs, ctx.comm_stats())
+        ctx.close()
+    except BaseException as e:          # a rank that dies must not leave the others waiting at the barrier forever
+        out[rank] = e
+        try:
+            comm.group.barrier.abort()
+        except Exception:
+            pass
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("cvname,gates,table_size", [("bn254", 60, 16), ("bn254", 4000, 1024), ("bls12_381", 1000, 64),
+                                                     ("bn254", 60000, 1024)])
+def test_sharded_proof_bytes_equal_the_oracle(world, cvname, gates, table_size):
+    """`world` contexts on one GPU play the ranks (threads + in-process all-gather): SRS slices, sharded setup (the
+    VerifierKey commitments through the partial-sum exchange), two chained proofs with distinct witnesses.  Bytes on
+    every rank == oracle (oracle.plonk up to n = 4096, the array prover beyond)."""
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd import parallel as par
+    from oracle import fastplonk as FP
+    cv = F.CURVES[cvname]
+    css = [P.synthetic_circuit(cv, gates, table_size, seed=gates + 3, value_seed=k, n_public=3 if gates < 100 else 20)
+           for k in (1, 2)]
+    cs = css[0]
+    tau = 0xABC0 + world + gates
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    mont = lambda v: K.fr_to_mont(cv, v) if len(v) else np.zeros((0, 4), dtype=np.uint64)
+    evals = {k: mont(v) for k, v in P.setup_evals(be, cs).items()}
+    blinders = [field_elems(cv.fr.p, 900 + k, P.NUM_BLINDERS) for k in range(2)]
+    if n <= 4096:
+        pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+        want = [P.prove(be, [None] * (n + 8), pk, epk, vk, c_, P.new_seeded_transcript(cv, vk), b).serialize(cv)
+                for c_, b in zip(css, blinders)]
+    else:
+        keys = FP.setup(cv, srs_arr, n.bit_length() - 1, evals)
+        vk = keys.verifier_key(cv, cs.pi.keys())
+        want = [FP.prove(cv, srs_arr, keys, *[mont(w) for w in c_.wire_evals(c_.n_gates)], mont(c_.table), c_.pi,
+                         P.new_seeded_transcript(cv, vk), b) for c_, b in zip(css, blinders)]
+    jobs = []
+    for c_, b in zip(css, blinders):
+        a, b_, c = (mont(w) for w in c_.wire_evals(c_.n_gates))
+        pos = sorted(c_.pi)
+        jobs.append((a, b_, c, mont(c_.table), pos, mont([c_.pi[i] for i in pos]), mont(b)))
+    group = par.LocalGroup(world)
+    out = [None] * world
+    ths = [threading.Thread(target=_rank_job, args=(z, par, group.comm(r), cv, n, srs_arr, {"evals": evals}, vk, jobs, out,
+                                                    r, world, True)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+    for r in range(world):
+        assert not isinstance(out[r], BaseException) and out[r] is not None, out[r]
+        proofs, (calls, sent) = out[r]
+        assert proofs == want, r
+        # per proof: 4 partial-sum exchanges + the quotient exchange; setup: 2
+        assert calls == 2 + 5 * len(jobs)
+        assert sent >= len(jobs) * (4 * n // world) * 32
+
+
+def test_two_rank_rehearsal_over_gloo_processes():
+    """The same path with real processes and torch.distributed (gloo) between them: tests/sharded_worker.py is started
+    twice by torch.distributed.run; both ranks print the digest of their proof, which must be the oracle's."""
+    port = socket.socket()
+    port.bind(("127.0.0.1", 0))
+    pnum = port.getsockname()[1]
+    port.close()
+    env = dict(os.environ, ZKT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(pnum), os.path.join(ROOT, "tests", "sharded_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("SHARDED ")]
+    assert len(lines) == 2 and all(l.split()[2] == "OK" for l in lines), r.stdout[-2000:]
+
+
+def test_torch_comm_device_path_on_one_rank():
+    """parallel.TorchComm's device branch (raw HBM pointers dressed as tensors, in-place all_gather_into_tensor over
+    RCCL) cannot meet a second GPU here; with a world of one it must at least leave the library's buffer intact and
+    see the bytes the library wrote."""
+    import torch
+    import torch.distributed as dist
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd import parallel as par
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = par.TorchComm(dist, torch.device("cuda", 0))
+        assert comm.vt.device_buffers == 1
+        ctx = z.Context("bn254", 0)
+        data = np.arange(4096, dtype=np.uint64)
+        d = ctx.alloc(data.nbytes)
+        ctx.upload(d, data)
+        assert comm._all_gather(None, d, d, data.nbytes, 1, None) == 0          # in place, as the prover calls it
+        assert np.array_equal(ctx.download(d, data.shape), data)
+        seen = torch.as_tensor(par._DevBuf(d, data.nbytes), device=torch.device("cuda", 0)).cpu().numpy().view(np.uint64)
+        assert np.array_equal(seen, data)
+        host = (np.arange(192, dtype=np.uint8) * 3).astype(np.uint8)
+        recv = np.zeros(192, dtype=np.uint8)
+        assert comm._all_gather(None, host.ctypes.data, recv.ctypes.data, 192, 0, None) == 0
+        assert np.array_equal(recv, host)
+        ctx.free(d)
+        ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -140,3 +140,81 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _comm_worker(rank, world, port, q):
+    """The communicator a sharded proof uses (parallel.TorchComm -> zkt_comm_vtable), driven from the C side through
+    zkt_comm_selftest: the bytes of every rank come back in rank order on every rank."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import importlib
+    par = importlib.import_module("zkt_plonk_amd.parallel")
+    lib = importlib.import_module("zkt_plonk_amd._lib")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = par.TorchComm(dist)
+        ok = True
+        for nbytes in (1, 128, 6 * 192, 70000):
+            mine = bytes((rank * 37 + i) & 0xFF for i in range(nbytes))
+            got = lib.comm_selftest(comm.vt, mine)
+            want = b"".join(bytes((r * 37 + i) & 0xFF for i in range(nbytes)) for r in range(world))
+            ok = ok and got == want
+        q.put((rank, ok, comm.vt.world, comm.vt.device_buffers, comm.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_two_comm_vtable_round_trip():
+    sys.path.insert(0, ROOT)
+    import zkt_plonk_amd  # noqa: F401
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] == 2 and r[3] == 0 and r[4] == 4 for r in res)
+
+
+def test_class_decomposition_of_the_coset_matches_the_oracle():
+    """The index algebra a sharded proof rests on, with the oracle's transforms (no GPU): the outputs of the 4n coset
+    transform whose index is cls mod G are the coset transform of size 4n / G with shift g w_4n^cls of the polynomial
+    folded modulo X^(4n/G) - shift^(4n/G); "omega-next" (index + 4) stays in the class for G <= 4 and moves to class
+    (cls + 4) mod 8, entry i + (cls + 4) // 8, for G = 8."""
+    sys.path.insert(0, ROOT)
+    from oracle import fields as F
+    from oracle.ntt import Domain
+    from helpers import field_elems
+    cv = F.BN254
+    p = cv.fr.p
+    n = 16
+    big = Domain(cv.fr, 4 * n)
+    coeffs = field_elems(p, 5, n + 8)
+    full = big.coset_fft(coeffs)
+    w4n = big.group_gen
+    for G in (1, 2, 4, 8):
+        m = 4 * n // G
+        sub = Domain(cv.fr, m)
+        for cls in range(G):
+            shift = cv.fr.generator * pow(w4n, cls, p) % p
+            cm = pow(shift, m, p)
+            folded = [0] * m
+            for i, v in enumerate(coeffs):
+                folded[i % m] = (folded[i % m] + v * pow(cm, i // m, p)) % p
+            scaled = [v * pow(shift, i, p) % p for i, v in enumerate(folded)]
+            got = sub.fft(scaled)
+            assert got == full[cls::G], (G, cls)
+            # omega-next
+            for i in range(m):
+                t = (cls + G * i + 4) % (4 * n)
+                if G <= 4:
+                    assert t % G == cls and t // G == (i + 4 // G) % m
+                else:
+                    assert t % G == (cls + 4) % 8 and t // G == (i + (cls + 4) // 8) % m

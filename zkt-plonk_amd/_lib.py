@@ -89,6 +89,37 @@ def _bind_optional(L):
         L.zkt_msm_info.argtypes = [vp, ip, ip, ctypes.POINTER(ctypes.c_size_t)]
 
 
+ALL_GATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                 ctypes.c_int, ctypes.c_void_p)
+
+
+class CommVtable(ctypes.Structure):
+    """zkt_comm_vtable (include/zkt_plonk.h): the caller's all-gather for a proof sharded across GPUs."""
+    _fields_ = [("user", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
+                ("device_buffers", ctypes.c_int), ("all_gather", ALL_GATHER_CB)]
+
+
+def shard_range(total: int, rank: int, world: int):
+    lo, hi = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    L = lib()
+    L.zkt_shard_range.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.POINTER(ctypes.c_size_t)]
+    if L.zkt_shard_range(total, rank, world, ctypes.byref(lo), ctypes.byref(hi)):
+        raise ValueError("zkt_shard_range(%d, %d, %d)" % (total, rank, world))
+    return lo.value, hi.value
+
+
+def comm_selftest(vt: CommVtable, send: bytes) -> bytes:
+    """Gathers `send` from every rank through the vtable (host buffers): plumbing check, no GPU needed."""
+    L = lib()
+    L.zkt_comm_selftest.argtypes = [ctypes.POINTER(CommVtable), ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    recv = ctypes.create_string_buffer(len(send) * vt.world)
+    rc = L.zkt_comm_selftest(ctypes.byref(vt), send, recv, len(send))
+    if rc:
+        raise ZktError(rc, "zkt_comm_selftest")
+    return recv.raw
+
+
 class ProveInputs(ctypes.Structure):
     _fields_ = [("a_evals", ctypes.POINTER(ctypes.c_uint64)), ("b_evals", ctypes.POINTER(ctypes.c_uint64)),
                 ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),
@@ -265,6 +296,48 @@ class Context:
         calls, ms = ctypes.c_uint64(0), ctypes.c_double(0.0)
         self.check(self._L.zkt_profile_get(self._h, name.encode(), ctypes.byref(calls), ctypes.byref(ms)))
         return calls.value, ms.value
+
+    # -- one proof across several GPUs --------------------------------------------------------------
+    def set_comm(self, comm):
+        """Attach a communicator (an object with a `.vt` CommVtable, e.g. parallel.TorchComm) or detach with None.
+        Drops whatever SRS / circuit was loaded: keys are laid out for the rank's share."""
+        L = self._L
+        L.zkt_ctx_set_comm.argtypes = [ctypes.c_void_p, ctypes.POINTER(CommVtable)]
+        self._comm = comm                       # keeps the callback alive
+        self.check(L.zkt_ctx_set_comm(self._h, ctypes.byref(comm.vt) if comm is not None else None))
+
+    def comm_stats(self):
+        """-> (collective calls, bytes sent by this rank) since the communicator was attached."""
+        L = self._L
+        L.zkt_comm_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self.check(L.zkt_comm_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def srs_load_slice(self, pts_slice: np.ndarray, offset: int, total: int):
+        pts = np.ascontiguousarray(pts_slice, dtype=np.uint64).reshape(-1, 2 * self.fq_limbs)
+        L = self._L
+        L.zkt_srs_load_slice.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.c_size_t,
+                                         ctypes.c_size_t]
+        self.check(L.zkt_srs_load_slice(self._h, u64p(pts), offset, pts.shape[0], total))
+
+    def srs_generate_slice(self, tau: int, offset: int, count: int, total: int):
+        t = np.array([(tau >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        L = self._L
+        L.zkt_srs_generate_slice.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t,
+                                             ctypes.c_size_t, ctypes.c_size_t]
+        self.check(L.zkt_srs_generate_slice(self._h, u64p(t), offset, count, total))
+
+    def ntt_class(self, log_n: int, log_big: int, cls: int, arr: np.ndarray) -> np.ndarray:
+        """One GPU's share (output indices = cls mod 2^(log_big - log_n)) of the forward coset transform of size
+        2^log_big; `arr` may be longer than 2^log_n (folded)."""
+        arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty((1 << log_n, 4), dtype=np.uint64)
+        L = self._L
+        L.zkt_ntt_class.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                                    ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+        self.check(L.zkt_ntt_class(self._h, log_n, log_big, cls, u64p(arr), arr.shape[0], u64p(out)))
+        return out
 
     # -- device memory ------------------------------------------------------------------------
     def alloc(self, nbytes: int) -> int:

@@ -7,6 +7,9 @@
 
 namespace zkt {
 
+void circuit_release(zkt_ctx* c);   // prover.hip
+void msm_release(zkt_ctx* c);       // msm.hip
+
 int set_err(zkt_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
@@ -43,6 +46,45 @@ int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes) {
     int rc = dev_alloc(c, p, bytes);
     if (rc) return rc;
     *cur = bytes;
+    return ZKT_OK;
+}
+
+int comm_all_gather_host(zkt_ctx* c, const void* send, void* recv, size_t bytes) {
+    if (!c->sharded() || !c->comm.vt.all_gather) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "no communicator attached");
+    ++c->comm.calls;
+    c->comm.bytes += bytes;
+    if (c->comm.vt.all_gather(c->comm.vt.user, send, recv, bytes, 0, nullptr))
+        return set_err(c, ZKT_ERR_COMM, "communicator: all_gather (host) failed");
+    return ZKT_OK;
+}
+int comm_all_gather_dev(zkt_ctx* c, const void* d_send, void* d_recv, size_t bytes) {
+    if (!c->sharded() || !c->comm.vt.all_gather) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "no communicator attached");
+    const int world = c->comm.vt.world;
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    ++c->comm.calls;
+    c->comm.bytes += bytes;
+    if (c->comm.vt.device_buffers) {
+        if (c->comm.vt.all_gather(c->comm.vt.user, d_send, d_recv, bytes, 1, (void*)c->stream))
+            return set_err(c, ZKT_ERR_COMM, "communicator: all_gather (device) failed");
+        return ZKT_OK;
+    }
+    // host-only transport (gloo rehearsals, a foreign host): stage through pinned memory
+    const size_t need = bytes * (size_t)(world + 1);
+    if (c->comm.pinned_bytes < need) {
+        if (c->comm.pinned) (void)hipHostFree(c->comm.pinned);
+        c->comm.pinned = nullptr;
+        c->comm.pinned_bytes = 0;
+        ZKT_HIP(c, hipHostMalloc(&c->comm.pinned, need));
+        c->comm.pinned_bytes = need;
+    }
+    char* hs = (char*)c->comm.pinned;
+    char* hr = hs + bytes;
+    ZKT_HIP(c, hipMemcpyAsync(hs, d_send, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->comm.vt.all_gather(c->comm.vt.user, hs, hr, bytes, 0, nullptr))
+        return set_err(c, ZKT_ERR_COMM, "communicator: all_gather (staged) failed");
+    ZKT_HIP(c, hipMemcpyAsync(d_recv, hr, bytes * world, hipMemcpyHostToDevice, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
     return ZKT_OK;
 }
 
@@ -139,10 +181,48 @@ void zkt_ctx_destroy(zkt_ctx* c) {
     c->ntt_plans.clear();
     c->msm.reset();
     c->circuit.reset();
+    if (c->comm.pinned) (void)hipHostFree(c->comm.pinned);
     for (void* p : c->owned) (void)hipFree(p);
     c->owned.clear();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int zkt_ctx_set_comm(zkt_ctx* c, const zkt_comm_vtable* comm) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    if (comm && comm->world > 1) {
+        const int w = comm->world;
+        if ((w != 2 && w != 4 && w != 8) || comm->rank < 0 || comm->rank >= w || !comm->all_gather)
+            return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "communicator: world must be 1, 2, 4 or 8 with a valid rank and callback");
+    }
+    // keys are laid out for the rank's share: whatever was loaded for another layout goes
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    circuit_release(c);
+    msm_release(c);
+    c->comm.vt = zkt_comm_vtable{};
+    c->comm.vt.world = 1;
+    if (comm && comm->world > 1) c->comm.vt = *comm;
+    c->comm.calls = 0;
+    c->comm.bytes = 0;
+    return ZKT_OK;
+}
+int zkt_shard_range(size_t total, int rank, int world, size_t* lo, size_t* hi) {
+    if (world < 1 || rank < 0 || rank >= world || !lo || !hi) return ZKT_ERR_INVALID_ARGUMENT;
+    const size_t base = total / (size_t)world, rem = total % (size_t)world;
+    *lo = (size_t)rank * base + ((size_t)rank < rem ? (size_t)rank : rem);
+    *hi = *lo + base + ((size_t)rank < rem ? 1 : 0);
+    return ZKT_OK;
+}
+int zkt_comm_stats(zkt_ctx* c, uint64_t* calls, uint64_t* bytes_sent) {
+    if (!c || !calls || !bytes_sent) return ZKT_ERR_INVALID_ARGUMENT;
+    *calls = c->comm.calls;
+    *bytes_sent = c->comm.bytes;
+    return ZKT_OK;
+}
+int zkt_comm_selftest(const zkt_comm_vtable* comm, const void* send, void* recv, size_t bytes) {
+    if (!comm || !comm->all_gather || !send || !recv) return ZKT_ERR_INVALID_ARGUMENT;
+    return comm->all_gather(comm->user, send, recv, bytes, 0, nullptr) ? ZKT_ERR_COMM : ZKT_OK;
 }
 
 const char* zkt_last_error(const zkt_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -210,7 +290,7 @@ int zkt_dev_download(zkt_ctx* c, void* host, const void* dptr, size_t bytes) {
 int zkt_ntt_dev(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
     if (!c || !d_out || (!d_in && in_len)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
     (void)hipSetDevice(c->device);
-    return ntt_run(c, log_n, inverse, coset, d_in, in_len, d_out);
+    return ntt_run(c, log_n, inverse, coset ? 1 : 0, d_in, in_len, d_out);
 }
 
 int zkt_ntt(zkt_ctx* c, int log_n, int inverse, int coset, const uint64_t* in, size_t in_len, uint64_t* out) {
@@ -222,8 +302,23 @@ int zkt_ntt(zkt_ctx* c, int log_n, int inverse, int coset, const uint64_t* in, s
     int rc = ensure_buffer(c, &c->io_a, &c->io_a_bytes, n * 32);
     if (rc) return rc;
     if (in_len) ZKT_HIP(c, hipMemcpyAsync(c->io_a, in, in_len * 32, hipMemcpyHostToDevice, c->stream));
-    rc = ntt_run(c, log_n, inverse, coset, c->io_a, in_len, c->io_a);
+    rc = ntt_run(c, log_n, inverse, coset ? 1 : 0, c->io_a, in_len, c->io_a);
     if (rc) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(out, c->io_a, n * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+int zkt_ntt_class(zkt_ctx* c, int log_n, int log_big, int cls, const uint64_t* in, size_t in_len, uint64_t* out) {
+    if (!c || !out || (!in && in_len)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (log_n < 0 || log_n > 27) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize");
+    (void)hipSetDevice(c->device);
+    const size_t n = (size_t)1 << log_n;
+    int rc = ensure_buffer(c, &c->io_a, &c->io_a_bytes, (in_len > n ? in_len : n) * 32);
+    if (rc) return rc;
+    if ((rc = ensure_buffer(c, &c->io_b, &c->io_b_bytes, n * 32))) return rc;
+    if (in_len) ZKT_HIP(c, hipMemcpyAsync(c->io_a, in, in_len * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = ntt_run_class(c, log_n, log_big, cls, c->io_a, in_len, c->io_a, c->io_b))) return rc;
     ZKT_HIP(c, hipMemcpyAsync(out, c->io_a, n * 32, hipMemcpyDeviceToHost, c->stream));
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
     return ZKT_OK;

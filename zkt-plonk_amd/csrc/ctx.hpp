@@ -48,6 +48,15 @@ struct zkt_ctx {
     std::map<std::string, ProfSlot> prof;
     std::vector<hipEvent_t> event_pool;
 
+    // Communicator of a proof sharded across GPUs (zkt_ctx_set_comm); world == 1: single GPU
+    struct Comm {
+        zkt_comm_vtable vt{};
+        void* pinned = nullptr;      // staging of device exchanges when the communicator takes host buffers only
+        size_t pinned_bytes = 0;
+        uint64_t calls = 0, bytes = 0;
+    } comm;
+    bool sharded() const { return comm.vt.world > 1; }
+
     std::shared_ptr<zkt::MsmState> msm;
     uint64_t msm_epoch = 0;   // bumped by every MSM enqueue and SRS (re)load: work issued ahead of time is tied to it
     uint64_t srs_generation = 0;   // bumped by every SRS (re)load: cached commitments are tied to the key they were made under
@@ -77,6 +86,11 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// all-gather through the context's communicator: `bytes` per rank, rank order.  _host: host buffers;
+// _dev: device buffers, ordered after everything enqueued on the context's stream, complete on return
+int comm_all_gather_host(zkt_ctx* c, const void* send, void* recv, size_t bytes);
+int comm_all_gather_dev(zkt_ctx* c, const void* d_send, void* d_recv, size_t bytes);
+
 // grows *p to at least `bytes`
 int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes);
 int dev_alloc(zkt_ctx* c, void** p, size_t bytes);
@@ -85,6 +99,9 @@ void dev_free(zkt_ctx* c, void* p);
 // ntt.hip
 template <class P>
 Fe<P> root_of_unity(int log_n);
+// coset: 0 none, 1 the generator g, ntt_class_code(log_big, cls) a class of a larger coset (see ntt.hip)
 int ntt_run(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out);
+int ntt_class_code(int log_big, int cls);
+int ntt_run_class(zkt_ctx* c, int log_n, int log_big, int cls, const void* d_in, size_t in_len, void* d_out, void* d_fold);
 
 }  // namespace zkt

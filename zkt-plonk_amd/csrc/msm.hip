@@ -45,6 +45,8 @@ constexpr int MSM_HEAVY_BLOCKS = 512;
 
 struct MsmState {
     size_t count = 0;      // bases loaded
+    // index-range sharding: this GPU holds powers [slice_off, slice_off + count) of a key of `total`
+    size_t slice_off = 0, total = 0;
     int c = 0, W = 0;      // max window bits, windows
     MsmWindows win{};
     uint32_t* heavy = nullptr;  // [0] = count, [1..] = heavy bucket ids
@@ -92,12 +94,12 @@ struct MsmState {
 // out[i] = tau^i * G  (insecure test SRS with a known trapdoor; PC::setup is out of scope)
 template <class C>
 __global__ void k_srs_generate(Affine<typename C::Fq>* out, size_t count, Fe<typename C::Fr> tau_mont,
-                               Affine<typename C::Fq> g) {
+                               Affine<typename C::Fq> g, size_t first) {
     using Q = typename C::Fq;
     using R = typename C::Fr;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    Fe<R> s = fe_from_mont<R>(fe_pow_u64<R>(tau_mont, (uint64_t)i));
+    Fe<R> s = fe_from_mont<R>(fe_pow_u64<R>(tau_mont, (uint64_t)(first + i)));
     Xyzz<Q> acc = xyzz_identity<Q>();
     bool started = false;
 #pragma unroll 1
@@ -772,7 +774,7 @@ static int srs_finish(zkt_ctx* c) {
     return ZKT_OK;
 }
 
-static void msm_release(zkt_ctx* c) {
+void msm_release(zkt_ctx* c) {
     if (!c->msm) return;
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
@@ -788,12 +790,14 @@ static void msm_release(zkt_ctx* c) {
 }
 
 template <class C>
-static int srs_load_t(zkt_ctx* c, const void* src, size_t count, bool src_on_device) {
+static int srs_load_t(zkt_ctx* c, const void* src, size_t count, bool src_on_device, size_t slice_off = 0, size_t total = 0) {
     using Q = typename C::Fq;
     if (count == 0) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "empty SRS");
     msm_release(c);
     int rc = msm_setup<C>(c, count);
     if (rc) return rc;
+    c->msm->slice_off = slice_off;
+    c->msm->total = total ? total : count;
     ZKT_HIP(c, hipMemcpyAsync(c->msm->table, src, count * sizeof(Affine<Q>),
                               src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     return srs_finish<C>(c);
@@ -826,19 +830,21 @@ Affine<Bls381Fq> generator_mont<Bls381Curve>() {
 }
 
 template <class C>
-static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count) {
+static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t slice_off = 0, size_t total = 0) {
     using Q = typename C::Fq;
     using R = typename C::Fr;
     if (count == 0) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "empty SRS");
     msm_release(c);
     int rc = msm_setup<C>(c, count);
     if (rc) return rc;
+    c->msm->slice_off = slice_off;
+    c->msm->total = total ? total : count;
     Fe<R> tau;
     memcpy(tau.v, tau4, 32);
     tau = fe_to_mont<R>(tau);
     unsigned blocks = (unsigned)((count + 127) / 128);
     hipLaunchKernelGGL(k_srs_generate<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)c->msm->table, count, tau,
-                       generator_mont<C>());
+                       generator_mont<C>(), slice_off);
     ZKT_HIP(c, hipGetLastError());
     return srs_finish<C>(c);
 }
@@ -934,6 +940,36 @@ static int msm_collect(zkt_ctx* c, int slot, Affine<typename C::Fq>* out) {
     return ZKT_OK;
 }
 
+// Collects a batch of commitments whose points are sharded across the GPUs of the communicator by index range
+// (SURVEY.md 8e "MSM - one tiny exchange"): every rank contributes the XYZZ partial sum of its slice (the identity where
+// the polynomial does not reach into it, have[j] = false: no MSM was started in that slot), ONE all-gather moves the
+// k x world partial sums as raw bytes (a collective cannot reduce curve points), and each rank adds them in rank order and
+// normalises.  Every rank obtains the same k affine points, bit for bit.
+template <class C>
+static int msm_collect_sharded(zkt_ctx* c, const int* slots, const bool* have, int k, Affine<typename C::Fq>* out) {
+    using Q = typename C::Fq;
+    MsmState& st = *c->msm;
+    const int world = c->comm.vt.world;
+    std::vector<Xyzz<Q>> send(k), recv((size_t)k * world);
+    for (int j = 0; j < k; ++j) {
+        if (have[j]) {
+            ZKT_HIP(c, hipEventSynchronize(st.ev_done[slots[j]]));
+            st.pending[slots[j]] = false;
+            memcpy(&send[j], st.host_result[slots[j]], sizeof(Xyzz<Q>));
+        } else {
+            send[j] = xyzz_identity<Q>();
+        }
+    }
+    int rc = comm_all_gather_host(c, send.data(), recv.data(), (size_t)k * sizeof(Xyzz<Q>));
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j) {
+        Xyzz<Q> acc = xyzz_identity<Q>();
+        for (int r = 0; r < world; ++r) acc = xyzz_add<Q>(acc, recv[(size_t)r * k + j]);
+        out[j] = xyzz_to_affine_host<Q>(acc);
+    }
+    return ZKT_OK;
+}
+
 template <class C>
 static int msm_run_t(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy,
                      int* out_inf) {
@@ -983,6 +1019,32 @@ int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy) {
     return ZKT_OK;
 }
 
+int msm_end_sharded(zkt_ctx* c, const int* slots, const bool* have, int k, uint64_t* out_xy /* k x 12 words */) {
+    if (c->curve == ZKT_CURVE_BN254) {
+        std::vector<Affine<Bn254Fq>> a(k);
+        int rc = msm_collect_sharded<Bn254Curve>(c, slots, have, k, a.data());
+        if (rc) return rc;
+        for (int j = 0; j < k; ++j) {
+            memcpy(out_xy + 12 * j, a[j].x.v, 32);
+            memcpy(out_xy + 12 * j + 4, a[j].y.v, 32);
+        }
+        return ZKT_OK;
+    }
+    std::vector<Affine<Bls381Fq>> a(k);
+    int rc = msm_collect_sharded<Bls381Curve>(c, slots, have, k, a.data());
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j) {
+        memcpy(out_xy + 12 * j, a[j].x.v, 48);
+        memcpy(out_xy + 12 * j + 6, a[j].y.v, 48);
+    }
+    return ZKT_OK;
+}
+void msm_slice(zkt_ctx* c, size_t* off, size_t* count, size_t* total) {
+    *off = c->msm ? c->msm->slice_off : 0;
+    *count = c->msm ? c->msm->count : 0;
+    *total = c->msm ? c->msm->total : 0;
+}
+
 int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf) {
     if (c->curve == ZKT_CURVE_BN254) return msm_run_t<Bn254Curve>(c, d_scalars, n, base_off, mont, out_xy, out_inf);
     return msm_run_t<Bls381Curve>(c, d_scalars, n, base_off, mont, out_xy, out_inf);
@@ -994,13 +1056,13 @@ int msm_enqueue_only(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_of
     if (c->curve == ZKT_CURVE_BN254) return msm_enqueue<Bn254Curve>(c, d_scalars, n, base_off, mont);
     return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont);
 }
-int srs_load(zkt_ctx* c, const void* src, size_t count, bool on_device) {
-    if (c->curve == ZKT_CURVE_BN254) return srs_load_t<Bn254Curve>(c, src, count, on_device);
-    return srs_load_t<Bls381Curve>(c, src, count, on_device);
+int srs_load(zkt_ctx* c, const void* src, size_t count, bool on_device, size_t slice_off = 0, size_t total = 0) {
+    if (c->curve == ZKT_CURVE_BN254) return srs_load_t<Bn254Curve>(c, src, count, on_device, slice_off, total);
+    return srs_load_t<Bls381Curve>(c, src, count, on_device, slice_off, total);
 }
-int srs_generate(zkt_ctx* c, const uint64_t* tau4, size_t count) {
-    if (c->curve == ZKT_CURVE_BN254) return srs_generate_t<Bn254Curve>(c, tau4, count);
-    return srs_generate_t<Bls381Curve>(c, tau4, count);
+int srs_generate(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t slice_off = 0, size_t total = 0) {
+    if (c->curve == ZKT_CURVE_BN254) return srs_generate_t<Bn254Curve>(c, tau4, count, slice_off, total);
+    return srs_generate_t<Bls381Curve>(c, tau4, count, slice_off, total);
 }
 template <class Q>
 static void table_to_ark(Affine<Q>* pts, size_t count) {
@@ -1053,6 +1115,18 @@ int zkt_srs_generate(zkt_ctx* c, const uint64_t* tau_canonical4, size_t count) {
     if (!c || !tau_canonical4) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
     (void)hipSetDevice(c->device);
     return srs_generate(c, tau_canonical4, count);
+}
+int zkt_srs_load_slice(zkt_ctx* c, const uint64_t* g1_xy_mont_slice, size_t offset, size_t count, size_t total) {
+    if (!c || !g1_xy_mont_slice) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (offset > total || count > total - offset) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "slice outside the key");
+    (void)hipSetDevice(c->device);
+    return srs_load(c, g1_xy_mont_slice, count, false, offset, total);
+}
+int zkt_srs_generate_slice(zkt_ctx* c, const uint64_t* tau_canonical4, size_t offset, size_t count, size_t total) {
+    if (!c || !tau_canonical4) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (offset > total || count > total - offset) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "slice outside the key");
+    (void)hipSetDevice(c->device);
+    return srs_generate(c, tau_canonical4, count, offset, total);
 }
 int zkt_srs_download(zkt_ctx* c, size_t offset, size_t count, uint64_t* out_xy_mont) {
     if (!c || !out_xy_mont) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");

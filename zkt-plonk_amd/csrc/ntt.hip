@@ -400,6 +400,19 @@ static int table_to_fx(zkt_ctx* c, void* t, uint64_t n) {
     return ZKT_OK;
 }
 
+// Coset codes (the third key of a plan): 0 = none; 1 = the multiplicative generator g (ark-poly's coset_fft);
+// ntt_class_code(log_big, cls) = g * w_{2^log_big}^cls: the points of the 2^log_big coset whose index is cls modulo
+// 2^(log_big - log_n) -- the class of the big transform's outputs one GPU of a sharded proof owns.
+int ntt_class_code(int log_big, int cls) { return 2 + cls + 256 * log_big; }
+
+template <class P>
+static Fe<P> coset_shift(int code) {
+    Fe<P> g = fe_from_u32<P>(P::GENERATOR);
+    if (code <= 1) return g;
+    const int cls = (code - 2) & 255, log_big = (code - 2) >> 8;
+    return fe_mul<P>(g, fe_pow_u64<P>(root_of_unity<P>(log_big), (uint64_t)cls));
+}
+
 template <class P>
 static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>& pl) {
     pl.log_n = log_n;
@@ -409,7 +422,7 @@ static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>&
     const uint64_t N = (uint64_t)1 << log_n;
     Fe<P> w = root_of_unity<P>(log_n);
     if (inverse) w = fe_inv_host<P>(w);
-    Fe<P> g = fe_from_u32<P>(P::GENERATOR);
+    Fe<P> g = coset_shift<P>(coset);
     Fe<P> ginv = fe_inv_host<P>(g);
     Fe<P> one = fe_one<P>();
     Fe<P> ninv = one;
@@ -526,11 +539,11 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
     if (log_n > 27) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "domains above 2^27 are not supported");
     const uint64_t N = (uint64_t)1 << log_n;
     if (in_len > N) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "more coefficients than the domain size");
-    auto key = std::make_tuple(log_n, inverse ? 1 : 0, coset ? 1 : 0);
+    auto key = std::make_tuple(log_n, inverse ? 1 : 0, coset);
     auto it = c->ntt_plans.find(key);
     if (it == c->ntt_plans.end()) {
         auto holder = std::make_shared<NttPlan<P>>();
-        int rc = build_plan<P>(c, log_n, inverse ? 1 : 0, coset ? 1 : 0, *holder);
+        int rc = build_plan<P>(c, log_n, inverse ? 1 : 0, coset, *holder);
         if (rc) return rc;
         it = c->ntt_plans.emplace(key, std::static_pointer_cast<void>(holder)).first;
     }
@@ -580,6 +593,47 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
 int ntt_run(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
     if (c->curve == ZKT_CURVE_BN254) return ntt_run_t<Bn254Fr>(c, log_n, inverse, coset, d_in, in_len, d_out);
     return ntt_run_t<Bls381Fr>(c, log_n, inverse, coset, d_in, in_len, d_out);
+}
+
+// p(X) mod (X^N - cN): out[i] = sum_k cN^k in[i + k N].  A polynomial longer than the class it is evaluated on
+// (n + 8 blinded coefficients on a class of n or n / 2 points) is folded first; cN = shift^N.
+template <class P>
+__global__ void k_fold(const Fe<P>* in, uint64_t in_len, Fe<P>* out, uint64_t N, Fe<P> cN) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Fe<P> acc = (i < in_len) ? fe_load<P>(in + i) : fe_zero<P>();
+    Fe<P> pw = cN;
+    for (uint64_t at = i + N; at < in_len; at += N) {
+        acc = fe_add<P>(acc, fe_mul<P>(pw, fe_load<P>(in + at)));
+        pw = fe_mul<P>(pw, cN);
+    }
+    fe_store<P>(out + i, acc);
+}
+
+template <class P>
+static int ntt_run_class_t(zkt_ctx* c, int log_n, int log_big, int cls, const void* d_in, size_t in_len, void* d_out,
+                           void* d_fold) {
+    const uint64_t N = (uint64_t)1 << log_n;
+    if (log_big < log_n || log_big > P::TWO_ADICITY || cls < 0 || cls >= (1 << (log_big - log_n)) || cls > 255)
+        return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "class transform: bad (log_n, log_big, class)");
+    const int code = (log_big == log_n) ? 1 : ntt_class_code(log_big, cls);
+    if (in_len > N) {
+        if (!d_fold) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "class transform: fold scratch missing");
+        const Fe<P> cN = fe_pow_u64<P>(coset_shift<P>(code), N);
+        hipLaunchKernelGGL(k_fold<P>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (const Fe<P>*)d_in,
+                           (uint64_t)in_len, (Fe<P>*)d_fold, N, cN);
+        ZKT_HIP(c, hipGetLastError());
+        d_in = d_fold;
+        in_len = N;
+    }
+    return ntt_run_t<P>(c, log_n, 0, code, d_in, in_len, d_out);
+}
+
+// One GPU's share of the forward coset transform of size 2^log_big sharded by output index over G = 2^(log_big - log_n)
+// GPUs: out[i] = p(g * w_big^(cls + G i)), i < 2^log_n.  in_len may exceed 2^log_n (d_fold: 2^log_n elements of scratch).
+int ntt_run_class(zkt_ctx* c, int log_n, int log_big, int cls, const void* d_in, size_t in_len, void* d_out, void* d_fold) {
+    if (c->curve == ZKT_CURVE_BN254) return ntt_run_class_t<Bn254Fr>(c, log_n, log_big, cls, d_in, in_len, d_out, d_fold);
+    return ntt_run_class_t<Bls381Fr>(c, log_n, log_big, cls, d_in, in_len, d_out, d_fold);
 }
 
 }  // namespace zkt

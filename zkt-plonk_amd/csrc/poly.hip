@@ -316,6 +316,8 @@ struct QuotientDev {
     uint64_t n4;
     const uint32_t* pi_tab;
     uint32_t n_pi_direct;
+    uint32_t G, cls, next_off;
+    const void *z1_next, *z2_next, *t_next, *h1_next;
 };
 template <class P>
 ZKT_D Fx<P> arg_fx(const FxArg& w) {
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
     typedef Fx<P> X;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.n4) return;
-    const uint64_t j = (i + 4 < q.n4) ? i + 4 : i + 4 - q.n4;  // "omega-next" on the 4n coset
+    // "omega-next": global index + 4, i.e. entry i + next_off of the (possibly neighbouring) class, wrapping
+    const uint64_t j = (i + q.next_off < q.n4) ? i + q.next_off : i + q.next_off - q.n4;
 #define LD(ptr, idx) fx_unpack<P>(fe_load<P>((const Fe<P>*)(ptr) + (idx)))   // canonical, < p
     const X beta = arg_fx<P>(q.beta), delta = arg_fx<P>(q.delta), gamma = arg_fx<P>(q.gamma);
     const X a = LD(q.a, i), b = LD(q.b, i), c = LD(q.c, i);
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
         acc = fx_add<P>(acc, fx_add<P>(LD(q.q_c, i), LD(q.pi, i)));             // < 6p
     }
     // keys/permutation.rs:97-137
-    const X z1 = LD(q.z1, i), z1n = LD(q.z1, j);
+    const X z1 = LD(q.z1, i), z1n = LD(q.z1_next, j);
     const X ag = fx_add<P>(a, gamma), bg = fx_add<P>(b, gamma), cg = fx_add<P>(c, gamma);   // < 2p
     const X one = fx_const_to_ark<P>();                                          // 1 in A form
     {
@@ -382,8 +385,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
     }
     {   // keys/lookup.rs:81-122
         const X eps = arg_fx<P>(q.epsilon), eopd = arg_fx<P>(q.eopd);
-        const X z2 = LD(q.z2, i), z2n = LD(q.z2, j);
-        const X t = LD(q.t, i), tn = LD(q.t, j), h1 = LD(q.h1, i), h1n = LD(q.h1, j), h2 = LD(q.h2, i);
+        const X z2 = LD(q.z2, i), z2n = LD(q.z2_next, j);
+        const X t = LD(q.t, i), tn = LD(q.t_next, j), h1 = LD(q.h1, i), h1n = LD(q.h1_next, j), h2 = LD(q.h2, i);
         X k1 = fx_mul<P>(z2, arg_fx<P>(q.alpha3_opd_k2));
         k1 = fx_mul<P>(k1, fx_add<P>(eps, fx_mul<P>(c, LD(q.q_lookup, i))));
         X k2 = fx_mul<P>(z2n, arg_fx<P>(q.alpha3_k2));
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
         acc = fx_add<P>(acc, fx_add<P>(fx_add<P>(k12, l13), k4));   // < 29p in all, times zh_inv < p: fits R' p (70 p on BLS12-381)
     }
 #undef LD
-    // quotient_poly.rs:220-224: times zh_coset[i]^-1; x^n - 1 takes 4 values on the 4n coset
-    const X r = fx_mul<P>(acc, arg_fx<P>(q.zh_inv[i & 3]));
+    // quotient_poly.rs:220-224: times zh_coset[i]^-1; x^n - 1 takes 4 values on the 4n coset (global index mod 4)
+    const X r = fx_mul<P>(acc, arg_fx<P>(q.zh_inv[(q.cls + q.G * (uint32_t)i) & 3]));
     fe_store<P>((Fe<P>*)q.out + i, fx_pack<P>(fx_cond_sub_p<P>(r)));
 }
 
@@ -797,6 +800,13 @@ template <class P> static int quotient_t(zkt_ctx* c, const QuotientArgs& a) {
     q.n4 = a.n4;
     q.pi_tab = a.pi_tab;
     q.n_pi_direct = a.n_pi_direct;
+    if (a.G <= 1) {
+        q.G = 1; q.cls = 0; q.next_off = 4;
+        q.z1_next = a.z1; q.z2_next = a.z2; q.t_next = a.t; q.h1_next = a.h1;
+    } else {
+        q.G = a.G; q.cls = a.cls; q.next_off = a.next_off;
+        q.z1_next = a.z1_next; q.z2_next = a.z2_next; q.t_next = a.t_next; q.h1_next = a.h1_next;
+    }
     if (a.pi_tab && a.n_pi_direct > (uint32_t)QUOTIENT_PI_DIRECT_MAX)
         return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "too many direct public inputs");
     hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(a.n4)), dim3(256), 0, c->stream, q);
@@ -811,6 +821,23 @@ template <class P> static int to_hat_t(zkt_ctx* c, void* v, size_t n, int k32) {
 }
 int to_hat_form(zkt_ctx* c, void* v, size_t n, int k32) { ZKT_DISPATCH(c, to_hat_t, v, n, k32); }
 int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a) { ZKT_DISPATCH(c, quotient_t, a); }
+
+// after the all-gather of a sharded proof: class-major -> natural order of the 4n coset
+template <class P>
+__global__ void k_interleave(const Fe<P>* in, Fe<P>* out, uint64_t n4, uint32_t log_g) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // natural index: coalesced writes
+    if (t >= n4) return;
+    const uint64_t cls = t & ((1u << log_g) - 1), i = t >> log_g;
+    fe_store<P>(out + t, fe_load<P>(in + cls * (n4 >> log_g) + i));
+}
+template <class P> static int interleave_t(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G) {
+    uint32_t lg = 0;
+    while ((1u << lg) < G) ++lg;
+    hipLaunchKernelGGL(k_interleave<P>, dim3(nblocks(n4)), dim3(256), 0, c->stream, (const Fe<P>*)in, (Fe<P>*)out, (uint64_t)n4, lg);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+int quotient_interleave(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G) { ZKT_DISPATCH(c, interleave_t, in, out, n4, G); }
 
 // prove.rs:287-289: the three (n+2)-coefficient chunks of the quotient, each zero-padded to its buffer
 template <class P>

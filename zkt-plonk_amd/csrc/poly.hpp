@@ -33,6 +33,13 @@ struct QuotientArgs {           // all vectors hold 4n coset evaluations
     // {4 pos_i, nine 29-bit limbs of v_i (arkworks Montgomery form)}; `pi` is ignored when pi_tab is set.
     const uint32_t* pi_tab;
     uint32_t n_pi_direct;
+    // Class form (one GPU's share of the 4n coset in a proof sharded over G GPUs, include/zkt_plonk.h): the vectors hold
+    // the n4 = 4n / G points of global index cls + G i.  "omega-next" (global index + 4) of point i is entry
+    // (i + next_off) mod n4 of the *_next vectors: the same vectors with next_off = 4 / G for G <= 4, the neighbouring
+    // class (cls + 4) mod 8 with next_off = (cls + 4) / 8 for G = 8.  zh_inv is indexed by the global index mod 4; the
+    // rotations in pi_tab are in class entries (4 pos / G).  G = 0 means the whole coset (G = 1, cls = 0, next_off = 4).
+    uint32_t G, cls, next_off;
+    const void *z1_next, *z2_next, *t_next, *h1_next;
 };
 constexpr int QUOTIENT_PI_DIRECT_MAX = 16;
 
@@ -70,6 +77,8 @@ int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a);
 // in place: arkworks Montgomery form -> the quotient kernel's R' = 2^261 form times 32^k32 (k32 in {0, 1}).
 // quotient_pointwise expects q_l q_r q_o q_lookup q_table l1 with k32 = 0 and q_m with k32 = 1.
 int to_hat_form(zkt_ctx* c, void* v, size_t n, int k32);
+// class-major (rank r's n4 / G points at [r * n4 / G, ...)) -> natural order of the 4n coset: out[cls + G i] = in[cls * (n4 / G) + i]
+int quotient_interleave(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G);
 int quotient_split_blind(zkt_ctx* c, const void* q, size_t n, const void* d_b0b1, void* q_lo, void* q_mid, void* q_hi,
                          uint32_t* d_status);                                                   // prove.rs:287-300
 // KZG opening witness: w = p / (X - z)  (kzg10::compute_witness_polynomial)

@@ -22,6 +22,8 @@ namespace zkt {
 int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf);
 int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot);
 int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy);
+int msm_end_sharded(zkt_ctx* c, const int* slots, const bool* have, int k, uint64_t* out_xy);
+void msm_slice(zkt_ctx* c, size_t* off, size_t* count, size_t* total);
 
 enum { PK_QM = 0, PK_QL, PK_QR, PK_QO, PK_QC, PK_S1, PK_S2, PK_S3, PK_QLOOKUP, PK_QTABLE, PK_COUNT };
 // coset vectors kept on the device (keys/mod.rs:153-174; x and l_1 are stored, zh is 4 scalars)
@@ -31,6 +33,14 @@ enum { W_A = 0, W_B, W_C, W_PI, W_Z1, W_Z2, W_T, W_H1, W_H2, W_COUNT };  // witn
 struct CircuitState {
     int log_n = 0;
     size_t n = 0;
+    // A proof sharded over G GPUs (zkt_ctx_set_comm): this GPU owns the 4n-coset points of global index cls modulo G,
+    // m = 4n / G of them; coset[] and wcos[] hold that class only.  G = 1: the whole coset, as the reference has it.
+    int G = 1, cls = 0, log_m = 0;
+    size_t m = 0;
+    void* wnext[4] = {};       // G = 8: z1, z2, t, h1 on the class (cls + 4) mod 8, where "omega-next" lives
+    void* fold = nullptr;      // m elements: a polynomial folded modulo X^m - shift^m before its class transform
+    void* qgather = nullptr;   // 4n elements: every rank's quotient evaluations, class-major (the all-gather's target)
+    bool have[16] = {};        // commitment slot -> this rank's SRS slice takes part (an MSM was started)
     void* pk[PK_COUNT] = {};
     size_t pk_len[PK_COUNT] = {};
     void* coset[CS_COUNT] = {};
@@ -176,19 +186,44 @@ struct Prover {
 
     // commitments of one round are enqueued back to back (the bucket-reduction tail of one overlaps the
     // accumulation of the next) and collected together
-    int commit_begin(const void* d_poly, size_t len, int slot) { return msm_begin(c, d_poly, len, 0, 1, slot); }
-    int commit_end(int slot, Affine<Q>* out) {
-        uint64_t xy[12];
-        int rc = msm_end(c, slot, xy);
-        if (rc) return rc;
-        memcpy(out->x.v, xy, Q::N * 4);
-        memcpy(out->y.v, xy + Q::N / 2, Q::N * 4);
-        return ZKT_OK;
+    // With the committer key sharded by index range, a commitment is this rank's partial sum over
+    // coefficients [slice_off, slice_off + slice_count) -- nothing at all when the polynomial ends below the slice.
+    int commit_begin(const void* d_poly, size_t len, int slot) {
+        if (!c->sharded()) return msm_begin(c, d_poly, len, 0, 1, slot);
+        size_t off, cnt, total;
+        msm_slice(c, &off, &cnt, &total);
+        if (len > total)
+            return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
+        S.have[slot] = len > off;
+        if (!S.have[slot]) return ZKT_OK;
+        const size_t l = std::min(len, off + cnt) - off;
+        return msm_begin(c, (const char*)d_poly + off * 32, l, 0, 1, slot);
     }
-    int commit(const void* d_poly, size_t len, Affine<Q>* out) {
-        int rc = commit_begin(d_poly, len, 0);
+    // The commitments of one prover round, collected together; skip[j]: nothing was started for entry j (out[j] is left
+    // alone).  Sharded: ONE all-gather of the round's partial sums (msm.hip msm_collect_sharded).
+    int commit_collect(const int* slots, const bool* skip, int k, Affine<Q>* out) {
+        if (!c->sharded()) {
+            for (int j = 0; j < k; ++j) {
+                if (skip && skip[j]) continue;
+                uint64_t xy[12];
+                int rc = msm_end(c, slots[j], xy);
+                if (rc) return rc;
+                memcpy(out[j].x.v, xy, Q::N * 4);
+                memcpy(out[j].y.v, xy + Q::N / 2, Q::N * 4);
+            }
+            return ZKT_OK;
+        }
+        bool have[16];
+        uint64_t xy[16 * 12];
+        for (int j = 0; j < k; ++j) have[j] = !(skip && skip[j]) && S.have[slots[j]];
+        int rc = msm_end_sharded(c, slots, have, k, xy);   // the message has k entries on every rank, whatever `have` says
         if (rc) return rc;
-        return commit_end(0, out);
+        for (int j = 0; j < k; ++j) {
+            if (skip && skip[j]) continue;
+            memcpy(out[j].x.v, xy + 12 * j, Q::N * 4);
+            memcpy(out[j].y.v, xy + 12 * j + Q::N / 2, Q::N * 4);
+        }
+        return ZKT_OK;
     }
 
     // iNTT of n evaluations into a zero-tailed coefficient buffer, trim, blind (prove.rs:120-127 etc.)
@@ -306,7 +341,13 @@ struct Prover {
         // challenge, so each is issued right behind the commitment of its polynomial, where it hides the latency-bound
         // tail of the last MSM of the round (which runs on the side stream).
         static const int coset_src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
-        return ntt_run(c, S.log_n + 2, 0, 1, S.poly[coset_src[k]], S.n + 8, S.wcos[k]);
+        if (S.G == 1) return ntt_run(c, S.log_n + 2, 0, 1, S.poly[coset_src[k]], S.n + 8, S.wcos[k]);
+        // sharded proof: only this GPU's class of the 4n coset, one m-point transform, no exchange
+        int rc = ntt_run_class(c, S.log_m, S.log_n + 2, S.cls, S.poly[coset_src[k]], S.n + 8, S.wcos[k], S.fold);
+        if (rc || S.G < 8) return rc;
+        static const int next_of[W_COUNT] = {-1, -1, -1, -1, 0, 1, 2, 3, -1};     // z1 z2 t h1 are read at "omega-next"
+        if (next_of[k] < 0) return ZKT_OK;
+        return ntt_run_class(c, S.log_m, S.log_n + 2, (S.cls + 4) & 7, S.poly[coset_src[k]], S.n + 8, S.wnext[next_of[k]], S.fold);
     }
 
     void swap_work_sets() {   // current <-> alternate copies of what early work of the next proof overwrites
@@ -417,16 +458,14 @@ struct Prover {
             tr.append_scalars("pi", b.data(), in.n_pi, 32, false);
         }
         Affine<Q> cm[11];
-        static const char* L1[3] = {"a_commit", "b_commit", "c_commit"};
         mark("enqueue rounds 1+2");
-        for (int k = 0; k < 3; ++k) {
-            if ((rc = commit_end(k, &cm[k]))) return rc;
-            if (k == 0) mark("wait a_commit");
-            tr_commit(L1[k], cm[k]);
+        {
+            static const int slots[6] = {0, 1, 2, 3, 4, 5};
+            const bool skip[6] = {false, false, false, same_table, false, false};
+            if ((rc = commit_collect(slots, skip, 6, cm))) return rc;
         }
-        mark("b c commits");
+        mark("wait commits of rounds 1+2");
         if (!same_table) {
-            if ((rc = commit_end(3, &cm[3]))) return rc;
             memcpy(S.t_commit_xy, cm[3].x.v, Q::N * 4);
             memcpy(S.t_commit_xy + Q::N / 2, cm[3].y.v, Q::N * 4);
             S.cached_table.assign(in.table, in.table + 4 * in.table_len);
@@ -436,11 +475,9 @@ struct Prover {
             memcpy(cm[3].x.v, S.t_commit_xy, Q::N * 4);
             memcpy(cm[3].y.v, S.t_commit_xy + Q::N / 2, Q::N * 4);
         }
-        for (int k = 1; k < 3; ++k) if ((rc = commit_end(3 + k, &cm[3 + k]))) return rc;
-        tr_commit("t_commit", cm[3]);
-        tr_commit("h1_commit", cm[4]);
-        tr_commit("h2_commit", cm[5]);
-        mark("t h1 h2 commits");
+        static const char* L12[6] = {"a_commit", "b_commit", "c_commit", "t_commit", "h1_commit", "h2_commit"};
+        for (int k = 0; k < 6; ++k) tr_commit(L12[k], cm[k]);
+        mark("transcript rounds 1+2");
 
         // ---- round 3 (prove.rs:190-255) ----
         const F beta = tr_challenge("beta"), gamma = tr_challenge("gamma"), delta = tr_challenge("delta"),
@@ -490,11 +527,12 @@ struct Prover {
         // public inputs it is never built: the quotient kernel evaluates it from rotations of l1 (poly.hpp).
         for (size_t i = 0; i < in.n_pi; ++i)
             if (in.pi_pos[i] >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "public input position out of range");
-        const bool pi_direct = in.n_pi <= (size_t)QUOTIENT_PI_DIRECT_MAX;
+        // (with 8 GPUs a rotation by 4 pos leaves the class for odd pos: the polynomial is transformed instead)
+        const bool pi_direct = in.n_pi <= (size_t)QUOTIENT_PI_DIRECT_MAX && S.G <= 4;
         if (pi_direct) {
             uint32_t* tab = (uint32_t*)S.pinned_pi;
             for (size_t i = 0; i < in.n_pi; ++i) {
-                tab[10 * i] = (uint32_t)(4 * in.pi_pos[i]);
+                tab[10 * i] = (uint32_t)(4 * in.pi_pos[i] / (size_t)S.G);   // rotation in entries of the class
                 const Fx<R> v = fx_unpack<R>(H::from_words(in.pi_vals + 4 * i));
                 for (int w = 0; w < 9; ++w) tab[10 * i + 1 + w] = v.l[w];
             }
@@ -507,7 +545,10 @@ struct Prover {
             if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[8], 0, 0, 8))) return rc;      // pi
             if ((rc = to_coset(W_PI))) return rc;
         }
-        for (int k = 0; k < 2; ++k) if ((rc = commit_end(k, &cm[6 + k]))) return rc;
+        {
+            static const int slots[2] = {0, 1};
+            if ((rc = commit_collect(slots, nullptr, 2, cm + 6))) return rc;
+        }
         tr_commit("z1_commit", cm[6]);
         tr_commit("z2_commit", cm[7]);
         mark("round 3 finish + commits");
@@ -526,10 +567,26 @@ struct Prover {
             q.out = S.qev;
             put(q.alpha, alpha); put(q.beta, beta); put(q.gamma, gamma); put(q.delta, delta); put(q.epsilon, epsilon);
             memcpy(q.zh_inv, S.zh_inv, sizeof(q.zh_inv));
-            q.n4 = 4 * n;
+            q.n4 = S.m;
             q.pi_tab = pi_direct ? S.pi_tab : nullptr;
             q.n_pi_direct = pi_direct ? (uint32_t)in.n_pi : 0;
-            if ((rc = quotient_pointwise(c, q))) return rc;
+            if (S.G > 1) {
+                // this GPU's class of the coset, written where the all-gather wants it; then the one real exchange of a
+                // sharded proof: 4n x 32 B in total, and the classes go back to natural order for the inverse transform
+                q.G = (uint32_t)S.G;
+                q.cls = (uint32_t)S.cls;
+                q.next_off = S.G <= 4 ? 4u / (uint32_t)S.G : (uint32_t)((S.cls + 4) >> 3);
+                q.z1_next = S.G == 8 ? S.wnext[0] : q.z1;
+                q.z2_next = S.G == 8 ? S.wnext[1] : q.z2;
+                q.t_next = S.G == 8 ? S.wnext[2] : q.t;
+                q.h1_next = S.G == 8 ? S.wnext[3] : q.h1;
+                q.out = (char*)S.qgather + (size_t)S.cls * S.m * 32;
+                if ((rc = quotient_pointwise(c, q))) return rc;
+                if ((rc = comm_all_gather_dev(c, q.out, S.qgather, S.m * 32))) return rc;
+                if ((rc = quotient_interleave(c, S.qgather, S.qev, 4 * n, (uint32_t)S.G))) return rc;
+            } else if ((rc = quotient_pointwise(c, q))) {
+                return rc;
+            }
             if ((rc = ntt_run(c, log_n + 2, 1, 1, S.qev, 4 * n, S.qev))) return rc;         // quotient_poly.rs:226
             if ((rc = quotient_split_blind(c, S.qev, n, (const char*)S.small + 17 * 32, S.poly[9], S.poly[10], S.poly[11], S.status)))
                 return rc;
@@ -543,7 +600,10 @@ struct Prover {
             swap_work_sets();
             S.prefetch_stage = (r1 == ZKT_OK) ? 1 : 0;   // on failure the next zkt_prove redoes the work and reports
         }
-        for (int k = 0; k < 3; ++k) if ((rc = commit_end(8 + k, &cm[8 + k]))) return rc;
+        {
+            static const int slots[3] = {8, 9, 10};
+            if ((rc = commit_collect(slots, nullptr, 3, cm + 8))) return rc;
+        }
         tr_commit("q_lo_commit", cm[8]);
         tr_commit("q_mid_commit", cm[9]);
         tr_commit("q_hi_commit", cm[10]);
@@ -691,8 +751,13 @@ struct Prover {
                     S.prefetch_stage = 0;
                 }
             }
-            if ((rc = commit_end(6, &aw))) return rc;
-            if ((rc = commit_end(7, &saw))) return rc;
+            {
+                static const int slots[2] = {6, 7};
+                Affine<Q> w2[2];
+                if ((rc = commit_collect(slots, nullptr, 2, w2))) return rc;
+                aw = w2[0];
+                saw = w2[1];
+            }
         }
 
         // ---- Proof (proof.rs:106-155), CanonicalSerialize ----
@@ -714,7 +779,7 @@ struct Prover {
 };
 
 // ---- circuit (ProverKey + ExtendedProverKey) ------------------------------------------------------
-static void circuit_release(zkt_ctx* c) {
+void circuit_release(zkt_ctx* c) {
     if (!c->circuit) return;
     (void)hipStreamSynchronize(c->stream);
     CircuitState& S = *c->circuit;
@@ -728,6 +793,8 @@ static void circuit_release(zkt_ctx* c) {
     fr(S.scan_tmp);
     for (void* p : S.poly) fr(p);
     for (void* p : S.wcos) fr(p);
+    for (void* p : S.wnext) fr(p);
+    fr(S.fold); fr(S.qgather);
     for (void* p : S.poly_alt) fr(p);
     fr(S.status_alt);
     fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
@@ -749,6 +816,12 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     S.log_n = log_n;
     const size_t n = (size_t)1 << log_n;
     S.n = n;
+    // sharded proof: this GPU keeps (and later transforms) only its class of the 4n coset
+    S.G = c->sharded() ? c->comm.vt.world : 1;
+    S.cls = c->sharded() ? c->comm.vt.rank : 0;
+    S.log_m = log_n + 2 - (S.G == 8 ? 3 : S.G == 4 ? 2 : S.G == 2 ? 1 : 0);
+    S.m = (size_t)1 << S.log_m;
+    const size_t m = S.m;
     int rc;
     auto alloc = [&](void** p, size_t elems) { return dev_alloc(c, p, elems * 32); };
     if ((rc = alloc(&S.qev, 4 * n))) return rc;
@@ -771,7 +844,12 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
             S.pk_len[k] = lens[k];
         }
     }
-    for (int k = 0; k < CS_COUNT; ++k) if ((rc = alloc(&S.coset[k], 4 * n))) return rc;
+    for (int k = 0; k < CS_COUNT; ++k) if ((rc = alloc(&S.coset[k], m))) return rc;
+    if (S.G > 1) {
+        if ((rc = alloc(&S.fold, m))) return rc;
+        if ((rc = alloc(&S.qgather, 4 * n))) return rc;
+        if (S.G == 8) for (auto& p : S.wnext) if ((rc = alloc(&p, m))) return rc;
+    }
     for (int k = 0; k < 3; ++k) if ((rc = alloc(&S.sigma_ev[k], n))) return rc;
     if ((rc = alloc(&S.q_lookup_ev, n))) return rc;
     if ((rc = alloc(&S.roots, n))) return rc;
@@ -779,7 +857,8 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     for (auto& p : S.sc) if ((rc = alloc(&p, n + 8))) return rc;
     if ((rc = alloc(&S.scan_tmp, 2 * ((n + 8) / 1024 + 4096)))) return rc;
     for (auto& p : S.poly) if ((rc = alloc(&p, n + 8))) return rc;
-    for (auto& p : S.wcos) if ((rc = alloc(&p, 4 * n))) return rc;
+    for (int k = 0; k < W_COUNT; ++k)   // the z1 slot doubles as 2n elements of scan scratch in round 3
+        if ((rc = alloc(&S.wcos[k], k == W_Z1 ? std::max(m, 2 * n) : m))) return rc;
     const size_t eval_blocks = (n + 8 + 2047) / 2048 + 1;
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
@@ -795,8 +874,12 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
 
     // extend_prover_key (keys/mod.rs:78-146) on the device
     const int pk_of_cs[10] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, PK_QLOOKUP, PK_QTABLE, PK_S1, PK_S2, PK_S3};
+    auto key_coset = [&](const void* poly, size_t len, void* out) {   // keys/mod.rs:98-120 coset_fft, this GPU's class
+        return S.G == 1 ? ntt_run(c, log_n + 2, 0, 1, poly, len, out)
+                        : ntt_run_class(c, S.log_m, log_n + 2, S.cls, poly, len, out, S.fold);
+    };
     for (int k = 0; k < 10; ++k)
-        if ((rc = ntt_run(c, log_n + 2, 0, 1, S.pk[pk_of_cs[k]], n, S.coset[k]))) return rc;
+        if ((rc = key_coset(S.pk[pk_of_cs[k]], n, S.coset[k]))) return rc;
     // sigma / q_lookup evaluations on the n domain (prove.rs:91-94)
     if ((rc = ntt_run(c, log_n, 0, 0, S.pk[PK_S1], n, S.sigma_ev[0]))) return rc;
     if ((rc = ntt_run(c, log_n, 0, 0, S.pk[PK_S2], n, S.sigma_ev[1]))) return rc;
@@ -806,19 +889,22 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     const F w = root_of_unity<R>(log_n), w4n = root_of_unity<R>(log_n + 2);
     const F g = fe_from_u32<R>(R::GENERATOR);
     if ((rc = gen_powers(c, S.roots, n, w.v, one.v))) return rc;                 // domain.elements()
-    if ((rc = gen_powers(c, S.coset[CS_X], 4 * n, w4n.v, g.v))) return rc;       // x_coset = g * w4n^i (keys/mod.rs:110-113)
+    {   // x_coset = g * w4n^t (keys/mod.rs:110-113), t = cls + G i on this GPU
+        const F step = fe_pow_u64<R>(w4n, (uint64_t)S.G), first = fe_mul<R>(g, fe_pow_u64<R>(w4n, (uint64_t)S.cls));
+        if ((rc = gen_powers(c, S.coset[CS_X], m, step.v, first.v))) return rc;
+    }
     {   // l_1_coset = coset_fft(L_1), L_1 = ifft(1, 0, ..., 0) = (1/n, ..., 1/n)  (keys/mod.rs:119-120)
         F nn = fe_zero<R>();
         nn.v[0] = (uint32_t)(n & 0xffffffffu);
         nn.v[1] = (uint32_t)((uint64_t)n >> 32);
         F ninv = fe_inv_host<R>(fe_to_mont<R>(nn));
         if ((rc = gen_powers(c, S.ev[0], n, one.v, ninv.v))) return rc;
-        if ((rc = ntt_run(c, log_n + 2, 0, 1, S.ev[0], n, S.coset[CS_L1]))) return rc;
+        if ((rc = key_coset(S.ev[0], n, S.coset[CS_L1]))) return rc;
     }
     // the tables that only ever multiply go to the quotient kernel's own Montgomery radix (poly.hpp)
-    if ((rc = to_hat_form(c, S.coset[CS_QM], 4 * n, 1))) return rc;
+    if ((rc = to_hat_form(c, S.coset[CS_QM], m, 1))) return rc;
     for (int k : {CS_QL, CS_QR, CS_QO, CS_QLOOKUP, CS_QTABLE, CS_L1})
-        if ((rc = to_hat_form(c, S.coset[k], 4 * n, 0))) return rc;
+        if ((rc = to_hat_form(c, S.coset[k], m, 0))) return rc;
     {   // zh_coset takes four values: (g * w4n^i)^n - 1 = g^n * w4^(i mod 4) - 1   (keys/mod.rs:115-117)
         const F gn = fe_pow_u64<R>(g, (uint64_t)n);
         const F w4 = fe_pow_u64<R>(w4n, (uint64_t)n);
@@ -846,16 +932,34 @@ static int circuit_setup_t(zkt_ctx* c, int log_n, const uint64_t* const* evals, 
     CircuitState& S = *c->circuit;
     // setup.rs:104-121: PC::commit of the ten labelled polynomials, ProverKey order; batches of the MSM's slot count
     const int L = Q::N / 2;
+    size_t off = 0, cnt = 0, total = 0;
+    msm_slice(c, &off, &cnt, &total);
+    if (c->sharded() && S.n > total)
+        return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
     for (int k0 = 0; k0 < PK_COUNT; k0 += 5) {
-        for (int k = k0; k < k0 + 5 && k < PK_COUNT; ++k)
-            if ((rc = msm_begin(c, S.pk[k], S.n, 0, 1, k - k0))) return rc;
-        for (int k = k0; k < k0 + 5 && k < PK_COUNT; ++k) {
-            uint64_t xy[12] = {};
-            if ((rc = msm_end(c, k - k0, xy))) return rc;
+        const int kk = std::min(5, PK_COUNT - k0);
+        uint64_t xy[5 * 12] = {};
+        if (!c->sharded()) {
+            for (int k = 0; k < kk; ++k)
+                if ((rc = msm_begin(c, S.pk[k0 + k], S.n, 0, 1, k))) return rc;
+            for (int k = 0; k < kk; ++k)
+                if ((rc = msm_end(c, k, xy + 12 * k))) return rc;
+        } else {   // this rank's slice of the coefficients; one all-gather per batch
+            int slots[5];
+            bool have[5];
+            for (int k = 0; k < kk; ++k) {
+                slots[k] = k;
+                have[k] = S.n > off;
+                if (have[k] && (rc = msm_begin(c, (const char*)S.pk[k0 + k] + off * 32, std::min(S.n, off + cnt) - off, 0, 1, k)))
+                    return rc;
+            }
+            if ((rc = msm_end_sharded(c, slots, have, kk, xy))) return rc;
+        }
+        for (int k = 0; k < kk; ++k) {
             bool inf = true;   // the identity comes back as (0, 0)
-            for (int i = 0; i < 2 * L; ++i) inf = inf && xy[i] == 0;
-            if (out_is_inf) out_is_inf[k] = inf ? 1 : 0;
-            for (int i = 0; i < 2 * L; ++i) out_commitments[(size_t)k * 2 * L + i] = xy[i];
+            for (int i = 0; i < 2 * L; ++i) inf = inf && xy[12 * k + i] == 0;
+            if (out_is_inf) out_is_inf[k0 + k] = inf ? 1 : 0;
+            for (int i = 0; i < 2 * L; ++i) out_commitments[(size_t)(k0 + k) * 2 * L + i] = xy[12 * k + i];
         }
     }
     return ZKT_OK;

@@ -5,7 +5,99 @@ GPUs, gloo in the CPU tests) only carries the barrier and the max-over-ranks tim
 partial sums as raw bytes and a local addition (a collective cannot reduce curve points)."""
 from __future__ import annotations
 
+import ctypes
+import sys
+import traceback
 from typing import List, Sequence, Tuple
+
+
+class _DevBuf:
+    """A raw device pointer dressed up for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    """zkt_comm_vtable over torch.distributed: the all-gather a proof sharded across the GPUs of a node needs
+    (include/zkt_plonk.h "one proof across the GPUs of a node").  backend "nccl" = RCCL over xGMI: the quotient exchange
+    moves device to device; the round's partial commitments (a few hundred bytes) bounce through a device tensor.
+    backend "gloo" (CPU tests, several ranks rehearsing on one GPU): host buffers only, the library stages the device
+    exchange through pinned memory."""
+
+    def __init__(self, dist, device=None):
+        import torch
+        from ._lib import CommVtable, ALL_GATHER_CB
+        self.dist = dist
+        self.torch = torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.nccl = dist.get_backend() == "nccl"
+        self.device = device
+        self.calls = 0
+        self._cb = ALL_GATHER_CB(self._all_gather)
+        self.vt = CommVtable(None, self.rank, self.world, 1 if self.nccl else 0, self._cb)
+
+    def _host(self, ptr, nbytes):
+        return self.torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=self.torch.uint8)
+
+    def _all_gather(self, user, send, recv, nbytes, on_device, stream):
+        try:
+            torch, dist = self.torch, self.dist
+            self.calls += 1
+            if on_device:
+                s = torch.as_tensor(_DevBuf(send, nbytes), device=self.device)
+                r = torch.as_tensor(_DevBuf(recv, nbytes * self.world), device=self.device)
+                dist.all_gather_into_tensor(r, s)
+                torch.cuda.synchronize(self.device)          # contract: complete when the callback returns
+                return 0
+            s, r = self._host(send, nbytes), self._host(recv, nbytes * self.world)
+            if self.nccl:
+                rd = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(rd, s.to(self.device))
+                r.copy_(rd.cpu())
+            else:
+                dist.all_gather([r[i * nbytes:(i + 1) * nbytes] for i in range(self.world)], s.clone())
+            return 0
+        except Exception:                                     # never let an exception cross the C boundary
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+
+class LocalGroup:
+    """Communicators for `world` contexts driven by threads of ONE process (one thread per GPU, or several contexts
+    rehearsing on one GPU in the tests): an in-process all-gather over host buffers; the library stages the device
+    exchange through pinned memory."""
+
+    def __init__(self, world: int):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [b""] * world
+
+    def comm(self, rank: int) -> "LocalComm":
+        return LocalComm(self, rank)
+
+
+class LocalComm:
+    def __init__(self, group: LocalGroup, rank: int):
+        from ._lib import CommVtable, ALL_GATHER_CB
+        self.group, self.rank, self.world = group, rank, group.world
+        self.calls = 0
+        self._cb = ALL_GATHER_CB(self._all_gather)
+        self.vt = CommVtable(None, rank, group.world, 0, self._cb)
+
+    def _all_gather(self, user, send, recv, nbytes, on_device, stream):
+        try:
+            g = self.group
+            self.calls += 1
+            g.slots[self.rank] = ctypes.string_at(send, nbytes)
+            g.barrier.wait(timeout=120)
+            ctypes.memmove(recv, b"".join(g.slots), nbytes * self.world)
+            g.barrier.wait(timeout=120)          # nobody overwrites a slot before everyone has read it
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            return 1
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
