@@ -160,6 +160,10 @@ def main():
     ap.add_argument("--curve", default="bn254", choices=sorted(FIELDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the cold / unchained single-proof legs")
+    ap.add_argument("--shard", default="both", choices=["proofs", "proof", "both"],
+                    help="N > 1: 'proofs' = independent proofs sharded across the GPUs (weak scaling, the headline); "
+                         "'proof' = ONE proof's MSMs and 4n-coset work sharded across the GPUs (strong scaling, value = "
+                         "1 / latency); 'both' (default) = the headline plus the single-proof leg in the same line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_workers(args, sys.argv[1:]))
@@ -202,6 +206,7 @@ def main():
     evals = {name: fr_to_mont_gpu(ctx, fld, circs[0]["sel"][name]) for name in z.PK_ORDER}
     prover, commits = z.GpuProver.setup(ctx, log_n, evals)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    evals_keep = evals if (world > 1 and args.shard != "proofs") else None
     if not want_cpu:
         del evals
     L = fld["fq_limbs"]
@@ -387,6 +392,18 @@ def main():
     if latency is not None:
         out["latency"] = latency
 
+    # ---- ONE proof across all the GPUs (SURVEY.md 8e / BASELINE.json configs[4]) -------------------------------------
+    if world > 1 and args.shard != "proofs":
+        refs = [ctx.prove_prepared(preps[k], transcript()) for k in range(2)]        # this GPU alone, for the bytes
+        try:
+            sh = sharded_leg(z, par, dist, dev, args, fld, tau, evals_keep, vk, host_w, table, pis, gates, refs, barrier)
+        except Exception as e:      # reported, never fatal for the headline
+            sh = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["single_proof_sharded"] = sh
+        if args.shard == "proof" and "ms_per_proof" in sh:
+            out.update(value=round(1e3 / sh["ms_per_proof"], 4), ms_per_step=sh["ms_per_proof"], scaling="strong")
+            out["config"]["parallelism"] = "one proof sharded across %d GPU(s)" % world
+
     if want_cpu:
         pi_pos, pi_vals, blinders = pis[0]
         gpu_proof = ctx.prove_prepared(preps[0], transcript())
@@ -396,6 +413,66 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis, gates, refs, barrier):
+    """ONE proof on all the GPUs of the job: every commitment is an index-range-sharded MSM (each rank keeps 1 / N of
+    the SRS, one all-gather of partial sums per prover round), the nine 4n-coset transforms and the quotient pass run on
+    the rank's class of the coset with no exchange, one all-gather (4n x 32 B in total) precedes the inverse transform;
+    the rest is replicated.  Same two witnesses, chained, as the headline; every rank checks its bytes against the
+    proofs it made alone."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    log_n, n = args.log_n, 1 << args.log_n
+    ctx = z.Context(args.curve, dev.index)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    comm = par.TorchComm(dist, dev)
+    ctx.set_comm(comm)
+    lo, hi = par.shard_range(n + 8, rank, world)
+    ctx.srs_generate_slice(tau, lo, hi - lo, n + 8)
+    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    L = fld["fq_limbs"]
+    preps = []
+    for hw, (pi_pos, pi_vals, blinders) in zip(host_w, pis):
+        dw = [torch.from_numpy(x.view(np.int64)).to(dev) for x in hw]
+        preps.append((ctx.prepare_dev(dw[0].data_ptr(), dw[1].data_ptr(), dw[2].data_ptr(), gates, table, pi_pos, pi_vals,
+                                      blinders), dw))
+
+    def transcript():
+        tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=fld["lam"], fq_bytes=8 * L)
+        return z.seed_transcript(tr, n, vk)
+
+    count = [0]
+
+    def one():
+        k = count[0] & 1
+        count[0] += 1
+        return k, ctx.prove_prepared(preps[k][0], transcript(), preps[k ^ 1][0])
+
+    ok = True
+    for _ in range(max(args.warmup, 2)):
+        k, pr = one()
+        ok = ok and pr == refs[k]
+    barrier()
+    calls0, bytes0 = ctx.comm_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        k, pr = one()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    barrier()
+    ok = ok and pr == refs[k]
+    calls1, bytes1 = ctx.comm_stats()
+    red_dev = dev if dist.get_backend() == "nccl" else None
+    dt = par.max_over_ranks(dist, dt, red_dev)
+    all_ok = par.max_over_ranks(dist, 0.0 if ok else 1.0, red_dev) == 0.0
+    info = ctx.msm_info()
+    ctx.close()
+    return {"ms_per_proof": round(1e3 * dt / args.steps, 3), "proofs_per_s": round(args.steps / dt, 4),
+            "proof_bytes_equal_single_gpu": bool(all_ok), "srs_points_per_gpu": hi - lo,
+            "msm_window_bits": info["window_bits"], "coset_points_per_gpu": 4 * n // world,
+            "collectives_per_proof": (calls1 - calls0) / args.steps,
+            "bytes_sent_per_gpu_per_proof": (bytes1 - bytes0) // args.steps, "backend": dist.get_backend()}
 
 
 def pmc_traffic(kernel, curve, log_n):

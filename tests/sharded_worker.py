@@ -26,6 +26,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group(backend)
+    if len(sys.argv) > 1 and sys.argv[1] == "devcomm":
+        return devcomm(torch, dist, z, par, dev)
     cv = F.BN254
     cs = P.synthetic_circuit(cv, 3000, 64, seed=12, value_seed=4)
     n = cs.circuit_bound()
@@ -48,6 +50,30 @@ def main():
     ctx.close()
     dist.destroy_process_group()
     sys.exit(0 if got == want else 1)
+
+
+def devcomm(torch, dist, z, par, dev):
+    """TorchComm's device branch with a world of one (RCCL): the library's HBM buffer dressed as a tensor, gathered in
+    place, must come back intact; the host branch bounces through a device tensor."""
+    device = torch.device("cuda", dev)
+    comm = par.TorchComm(dist, device)
+    assert comm.vt.device_buffers == 1
+    ctx = z.Context("bn254", dev)
+    data = np.arange(4096, dtype=np.uint64)
+    d = ctx.alloc(data.nbytes)
+    ctx.upload(d, data)
+    assert comm._all_gather(None, d, d, data.nbytes, 1, None) == 0          # in place, as the prover calls it
+    assert np.array_equal(ctx.download(d, data.shape), data)
+    seen = torch.as_tensor(par._DevBuf(d, data.nbytes), device=device).cpu().numpy().view(np.uint64)
+    assert np.array_equal(seen, data)
+    host = (np.arange(192, dtype=np.uint8) * 3).astype(np.uint8)
+    recv = np.zeros(192, dtype=np.uint8)
+    assert comm._all_gather(None, host.ctypes.data, recv.ctypes.data, 192, 0, None) == 0
+    assert np.array_equal(recv, host)
+    ctx.free(d)
+    ctx.close()
+    dist.destroy_process_group()
+    print("DEVCOMM OK", flush=True)
 
 
 if __name__ == "__main__":
