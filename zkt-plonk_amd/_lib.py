@@ -9,7 +9,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libzkt_plonk_hip.so")
+# ZKT_LIB_PATH: load another build of the same C-ABI (the host-side sanitizer build of tests/test_host_sanitize.py)
+_LIB = os.environ.get("ZKT_LIB_PATH") or os.path.join(_HERE, "libzkt_plonk_hip.so")
 _HEADER = os.path.join(_HERE, "..", "include", "zkt_plonk.h")
 
 CURVE_BN254 = 0
