@@ -263,6 +263,25 @@ int zkt_prove_set_next(zkt_ctx* ctx, const zkt_prove_inputs* next);
 int zkt_prove_with(zkt_ctx* ctx, const zkt_prove_inputs* in, const zkt_transcript_vtable* transcript,
                    uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 
+/* ---- key files of the reference CLI ------------------------------------------------------------
+ * `serialize_to_file` = CanonicalSerialize::serialize_unchecked (bin/src/parser.rs:14-22).  Layouts restated from
+ * ark-serialize / ark-poly-commit 0.3 (see csrc/keyfile.hip); the reference holds no key file, so these readers are
+ * pinned only by the round trip against the writer in oracle/keyfile.py ("parity unpinned").  Host-only; values come
+ * back as arkworks Montgomery limbs, ready for zkt_srs_load / zkt_circuit_load / zkt_transcript_seed. */
+/* --ck (bin/src/main.rs:105): SonicKZG10 CommitterKey -> powers_of_g[0 .. min(count, max_powers)); max_powers = 0: all.
+ * out_xy_mont = NULL: only *n_powers.  The prover needs n + 8 of the 4n + 1 powers the file holds. */
+int zkt_keyfile_committer_key(const char* path, int curve_id, size_t max_powers, uint64_t* out_xy_mont, size_t* n_powers);
+/* --pk (bin/src/main.rs:107): ProverKey<F> (keys/mod.rs:29-41) -> the ten coefficient vectors in zkt_circuit_load
+ * order and their lengths; out_polys = NULL (or an entry NULL): lengths only. */
+int zkt_keyfile_prover_key(const char* path, int curve_id, uint64_t* const* out_polys, size_t* lens10);
+/* --vk (bin/src/main.rs:111): VerifierKey (keys/mod.rs:180-210) -> n, pi_roots, the ten commitments (x, y) in
+ * zkt_transcript_seed order with their infinity flags. */
+int zkt_keyfile_verifier_key(const char* path, int curve_id, uint64_t* n, uint64_t* pi_roots_mont, size_t pi_cap, size_t* n_pi,
+                             uint64_t* commitments_xy_mont, int* is_infinity10);
+/* the two loads a prover service does at start-up, straight from the CLI's files */
+int zkt_srs_load_file(zkt_ctx* ctx, const char* ck_path, size_t max_powers);
+int zkt_circuit_load_file(zkt_ctx* ctx, const char* pk_path, int log_n);
+
 /* ---- debug / test support ------------------------------------------------------------------ */
 /* Dumps the compiled-in parameter tables (modulus, -p^-1 mod 2^32, R, R^2) as u32 words for
  * which = 0 (Fr) or 1 (Fq) of the context's curve; returns the limb count. */

@@ -616,3 +616,37 @@ def test_foreign_transcript_callbacks(ctxs):
     rc = L.zkt_prove_with(ctx.handle, ctypes.byref(inp), ctypes.byref(vt), out, 2048, ctypes.byref(ln))
     assert rc == 0, L.zkt_last_error(ctx.handle)
     assert bytes(out[:ln.value]) == want
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_prove_from_the_reference_cli_key_files(cv, ctxs, tmp_path):
+    """a prover service started from the files the reference CLI writes (bin/src/main.rs:105-111):
+    --ck -> zkt_srs_load_file, --pk -> zkt_circuit_load_file, --vk -> the transcript seed.  Files come from the oracle's
+    writers ("parity unpinned": the reference holds no key file); the proof must equal the oracle's bytes."""
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd import _lib
+    from oracle import keyfile as KF
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 1500, 64, seed=404)
+    n = cs.circuit_bound()
+    tau = 0xF11E5
+    srs_arr = K.srs_mont(cv, tau, 4 * n + 1)             # PC::trim keeps 4n + 1 powers (plonk.rs:79-85)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (4 * n + 1), cs, True)
+    blinders = field_elems(cv.fr.p, 61, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (4 * n + 1), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    (tmp_path / "ck").write_bytes(KF.committer_key_bytes(cv, K.points_from_mont(cv, srs_arr)))
+    (tmp_path / "pk").write_bytes(KF.prover_key_bytes(cv, pk))
+    (tmp_path / "vk").write_bytes(KF.verifier_key_bytes(cv, vk))
+    ctx.srs_load_file(str(tmp_path / "ck"), max_powers=n + 8)
+    assert ctx.msm_info()["srs_count"] == n + 8
+    ctx.circuit_load_file(str(tmp_path / "pk"), n.bit_length() - 1)
+    n_, roots, commits, inf = _lib.keyfile_verifier_key(str(tmp_path / "vk"), cv.name)
+    pts = {name: (None if inf[k] else K.points_from_mont(cv, commits[k:k + 1])[0]) for k, name in enumerate(z.PK_ORDER)}
+    tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+    z.seed_transcript(tr, n_, pts)
+    a, b, c = cs.wire_evals(cs.n_gates)
+    pos = sorted(cs.pi)
+    got = ctx.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table), pos,
+                    K.fr_to_mont(cv, [cs.pi[i] for i in pos]), K.fr_to_mont(cv, blinders), tr)
+    assert got == want

@@ -121,6 +121,64 @@ def comm_selftest(vt: CommVtable, send: bytes) -> bytes:
     return recv.raw
 
 
+def keyfile_committer_key(path: str, curve, max_powers: int = 0) -> np.ndarray:
+    """--ck file of the reference CLI -> powers_of_g as (count, 2*fq_limbs) Montgomery limbs (host only)."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    L.zkt_keyfile_committer_key.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.POINTER(ctypes.c_size_t)]
+    n = ctypes.c_size_t(0)
+    rc = L.zkt_keyfile_committer_key(path.encode(), cid, max_powers, None, ctypes.byref(n))
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_committer_key(%s)" % path)
+    out = np.zeros((n.value, words), dtype=np.uint64)
+    rc = L.zkt_keyfile_committer_key(path.encode(), cid, max_powers, u64p(out) if out.size else None, ctypes.byref(n))
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_committer_key(%s)" % path)
+    return out
+
+
+def keyfile_prover_key(path: str, curve):
+    """--pk file -> the ten coefficient arrays ((len_k, 4) Montgomery limbs) in zkt_circuit_load order (host only)."""
+    L = lib()
+    cid = curve_id(curve)
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_keyfile_prover_key.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(P64), ctypes.POINTER(ctypes.c_size_t)]
+    lens = (ctypes.c_size_t * 10)()
+    rc = L.zkt_keyfile_prover_key(path.encode(), cid, None, lens)
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_prover_key(%s)" % path)
+    arrs = [np.zeros((max(lens[k], 1), 4), dtype=np.uint64) for k in range(10)]
+    ptrs = (P64 * 10)(*[u64p(a) for a in arrs])
+    rc = L.zkt_keyfile_prover_key(path.encode(), cid, ptrs, lens)
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_prover_key(%s)" % path)
+    return [a[:lens[k]] for k, a in enumerate(arrs)]
+
+
+def keyfile_verifier_key(path: str, curve):
+    """--vk file -> (n, pi_roots (k, 4), commitments (10, 2*fq_limbs), is_infinity (10,)); Montgomery limbs (host only)."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_keyfile_verifier_key.argtypes = [ctypes.c_char_p, ctypes.c_int, P64, P64, ctypes.c_size_t,
+                                           ctypes.POINTER(ctypes.c_size_t), P64, ctypes.POINTER(ctypes.c_int)]
+    n, k = ctypes.c_uint64(0), ctypes.c_size_t(0)
+    rc = L.zkt_keyfile_verifier_key(path.encode(), cid, ctypes.byref(n), None, 0, ctypes.byref(k), None, None)
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_verifier_key(%s)" % path)
+    roots = np.zeros((max(k.value, 1), 4), dtype=np.uint64)
+    commits = np.zeros((10, words), dtype=np.uint64)
+    inf = (ctypes.c_int * 10)()
+    rc = L.zkt_keyfile_verifier_key(path.encode(), cid, ctypes.byref(n), u64p(roots), roots.shape[0], ctypes.byref(k),
+                                    u64p(commits), inf)
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_verifier_key(%s)" % path)
+    return n.value, roots[:k.value], commits, np.array([bool(x) for x in inf])
+
+
 class ProveInputs(ctypes.Structure):
     _fields_ = [("a_evals", ctypes.POINTER(ctypes.c_uint64)), ("b_evals", ctypes.POINTER(ctypes.c_uint64)),
                 ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),
@@ -378,6 +436,18 @@ class Context:
     def srs_load(self, pts: np.ndarray):
         pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 2 * self.fq_limbs)
         self.check(self._L.zkt_srs_load(self._h, u64p(pts), pts.shape[0]))
+
+    def srs_load_file(self, ck_path: str, max_powers: int = 0):
+        """zkt_srs_load from the reference CLI's --ck file (CommitterKey.powers_of_g)."""
+        L = self._L
+        L.zkt_srs_load_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        self.check(L.zkt_srs_load_file(self._h, ck_path.encode(), max_powers))
+
+    def circuit_load_file(self, pk_path: str, log_n: int):
+        """zkt_circuit_load from the reference CLI's --pk file (ProverKey<F>)."""
+        L = self._L
+        L.zkt_circuit_load_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        self.check(L.zkt_circuit_load_file(self._h, pk_path.encode(), log_n))
 
     def srs_generate(self, tau: int, count: int):
         t = np.array([(tau >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
