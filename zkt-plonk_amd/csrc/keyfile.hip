@@ -5,7 +5,7 @@
 //   * plonk-core's VerifierKey     (bin/src/main.rs:111 --vk; keys/mod.rs:180-210)       -> zkt_transcript_seed
 // Host-only code.  The byte layouts follow ark-serialize 0.3 / ark-poly-commit 0.3 (third-party crates absent from
 // /root/reference; restated from their published derive rules, no reference-held file exists to pin them against:
-// "parity unpinned", the round trip is tested against the writer in oracle/keyfile.py):
+// "parity unpinned", the round trip is tested against the writer of the test-side restatement):
 //   usize, u64                -> 8 bytes little endian          Vec<T> -> u64 length, then the elements
 //   String                    -> Vec<u8>                        Option<T> -> one byte (0 / 1), then T
 //   Fp256 / Fp384             -> canonical (non-Montgomery) value, little endian, 32 / 48 bytes
