@@ -2,6 +2,7 @@
 #include "ctx.hpp"
 #include "hostinv.hpp"
 #include "ec.hpp"
+#include "hostec.hpp"
 
 #include <cstring>
 
@@ -390,15 +391,16 @@ template <class C>
 static void g1_sum_host(const uint64_t* pts, size_t count, uint64_t* out, int* out_inf) {
     using Q = typename C::Fq;
     constexpr int L = Q::N / 2;   // u64 limbs per coordinate
-    Xyzz<Q> acc = xyzz_identity<Q>();
+    // the host's own 64-bit-limb arithmetic (hostec.hpp), the one that finishes every MSM's bucket reduction
+    hostec::HX<Q> acc = hostec::hx_identity<Q>();
     for (size_t i = 0; i < count; ++i) {
         Affine<Q> a;
         memcpy(a.x.v, pts + i * 2 * L, Q::N * 4);
         memcpy(a.y.v, pts + i * 2 * L + L, Q::N * 4);
         if (aff_is_inf<Q>(a)) continue;
-        acc = xyzz_add_mixed<Q>(acc, a);
+        acc = hostec::hx_add<Q>(acc, hostec::hx_from<Q>(xyzz_from_affine<Q>(a)));
     }
-    const Affine<Q> r = xyzz_to_affine_host<Q>(acc);
+    const Affine<Q> r = xyzz_to_affine_host<Q>(hostec::hx_to<Q>(acc));
     memcpy(out, r.x.v, Q::N * 4);
     memcpy(out + L, r.y.v, Q::N * 4);
     if (out_inf) *out_inf = aff_is_inf<Q>(r) ? 1 : 0;

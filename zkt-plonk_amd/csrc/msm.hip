@@ -19,6 +19,7 @@
 #include "ctx.hpp"
 #include "ec.hpp"
 #include "ecx.hpp"
+#include "hostec.hpp"
 
 #include <cstring>
 
@@ -72,8 +73,7 @@ struct MsmState {
     void* segA[SLOTS] = {};         // Xyzz[B / SEG]
     void* segT[SLOTS] = {};
     void* partials[SLOTS] = {};     // Xyzz[MAX_Y * R2_BLOCKS]
-    void* result[SLOTS] = {};       // Xyzz
-    void* host_result[SLOTS] = {};  // pinned
+    void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
     size_t acc_threads = 196608;   // resident threads of k_msm_accumulate (occupancy query at setup)
     hipStream_t side = nullptr;
     hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
@@ -612,49 +612,29 @@ __global__ __launch_bounds__(256) void k_msm_segments(const Xyzz<typename C::Fq>
     xx_store<Q>(segT + s, run);
 }
 
-// y = 0: plain sum of segA ; y = k + 1: sum of segT[s] over s with bit k set.  One partial per block.
+// y = 0: plain sum of segA ; y = k + 1 (< ny): sum of segT[s] over s with bit k set ; y = ny: the top bucket alone.
+// One partial per block, written in arkworks' R form: the host adds them up and applies the weights
+// (hostec.hpp weighted_row_sum) -- the remaining ~35 dependent curve operations cost a wavefront 0.6 ms and the host 15 us.
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::Fq>* segA,
-                                                         const Xyzz<typename C::Fq>* segT, uint32_t nseg,
+                                                         const Xyzz<typename C::Fq>* segT, uint32_t nseg, int ny,
+                                                         const Xyzz<typename C::Fq>* top_bucket,
                                                          Xyzz<typename C::Fq>* partials) {
     using Q = typename C::Fq;
     __shared__ Xyzz<Q> wsum[4];
     const int y = blockIdx.y;
+    if (y == ny) {
+        if (threadIdx.x == 0)
+            xx_store_ark<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, blockIdx.x == 0 ? xx_load<Q>(top_bucket) : xx_identity<Q>());
+        return;
+    }
     const Xyzz<Q>* src = (y == 0) ? segA : segT;
     XyzzX<Q> acc = xx_identity<Q>();
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
         if (y == 0 || ((s >> (y - 1)) & 1u)) acc = xx_add<Q>(acc, xx_load<Q>(src + s));
     }
     acc = block_sum_256<Q>(acc, wsum);
-    if (threadIdx.x == 0) xx_store<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
-}
-
-// result = sum_y 2^(e_y) * V_y ; V_y = sum of the y-th row of partials, plus the top bucket with e = c-1.
-// The result leaves in arkworks' R-Montgomery form.
-template <class C>
-__global__ __launch_bounds__(64) void k_msm_final(const Xyzz<typename C::Fq>* partials, int ny, int nblk,
-                                                  const Xyzz<typename C::Fq>* top_bucket, int c,
-                                                  Xyzz<typename C::Fq>* result) {
-    using Q = typename C::Fq;
-    const int y = threadIdx.x;
-    XyzzX<Q> v = xx_identity<Q>();
-    int e = 0;
-    if (y < ny) {
-        for (int j = 0; j < nblk; ++j) v = xx_add<Q>(v, xx_load<Q>(partials + (size_t)y * nblk + j));
-        e = (y == 0) ? 0 : (y - 1) + MSM_LOG_SEG;
-    } else if (y == ny) {
-        v = xx_load<Q>(top_bucket);
-        e = c - 1;
-    }
-#pragma unroll 1
-    for (int k = 0; k < e; ++k) v = xx_double<Q>(v);
-#pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
-        XyzzX<Q> o = xx_shfl_down<Q>(v, d);
-        if (y + d >= 64) o = xx_identity<Q>();
-        v = xx_add<Q>(v, o);
-    }
-    if (y == 0) xx_store_ark<Q>(result, v);
+    if (threadIdx.x == 0) xx_store_ark<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
 }
 
 // table: arkworks R form -> R' form (canonical packed), in place; (0,0) stays (0,0)
@@ -673,6 +653,9 @@ __global__ void k_srs_to_fx(Affine<typename C::Fq>* table, size_t total) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// rows of partial sums an MSM leaves for the host: row 0 (weight 1), one row per bit of the segment index, the top bucket
+static int msm_rows(int c) { return 1 + (c - 1 - MSM_LOG_SEG); }
+
 static int floor_log2(size_t x) {
     int l = 0;
     while ((x >> (l + 1)) != 0) ++l;
@@ -747,9 +730,8 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segA[i], nseg * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segT[i], nseg * sizeof(Xyzz<Q>)))) return rc;
-        if ((rc = dev_alloc(c, &st->partials[i], (size_t)MSM_MAX_Y * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)))) return rc;
-        if ((rc = dev_alloc(c, &st->result[i], sizeof(Xyzz<Q>)))) return rc;
-        ZKT_HIP(c, hipHostMalloc(&st->host_result[i], sizeof(Xyzz<Q>)));
+        if ((rc = dev_alloc(c, &st->partials[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)))) return rc;
+        ZKT_HIP(c, hipHostMalloc(&st->host_result[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)));
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_done[i], hipEventDisableTiming));
     }
@@ -784,7 +766,7 @@ void msm_release(zkt_ctx* c) {
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
-        dev_free(c, st.partials[i]); dev_free(c, st.result[i]);
+        dev_free(c, st.partials[i]);
     }
     c->msm.reset();
 }
@@ -849,7 +831,7 @@ static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t
     return srs_finish<C>(c);
 }
 
-// enqueue the whole MSM; the XYZZ result lands in st.result
+// enqueue the whole MSM; its partial sums land in st.host_result[slot] (pinned), see msm_host_finish
 template <class C>
 static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0) {
     using Q = typename C::Fq;
@@ -905,25 +887,37 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     // ---- tail on the side stream: overlaps whatever the main stream does next ----
     ZKT_HIP(c, hipEventRecord(st.ev_main[slot], c->stream));
     ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[slot], 0));
+    int ny = 0;
     {
     ProfScope prof_tail(c, "msm_tail", st.side);
     const uint32_t nseg = st.B / MSM_SEG;
     hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, st.side,
                        (const Xyzz<Q>*)st.buckets[slot], nseg, (Xyzz<Q>*)st.segA[slot], (Xyzz<Q>*)st.segT[slot]);
     ZKT_HIP(c, hipGetLastError());
-    int seg_bits = st.c - 1 - MSM_LOG_SEG;  // log2(nseg)
-    int ny = 1 + seg_bits;
-    hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny), dim3(256), 0, st.side,
-                       (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], nseg, (Xyzz<Q>*)st.partials[slot]);
-    ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_final<C>, dim3(1), dim3(64), 0, st.side, (const Xyzz<Q>*)st.partials[slot], ny,
-                       MSM_R2_BLOCKS, (const Xyzz<Q>*)st.buckets[slot] + st.B, st.c, (Xyzz<Q>*)st.result[slot]);
+    ny = msm_rows(st.c);
+    hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny + 1), dim3(256), 0, st.side,
+                       (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], nseg, ny,
+                       (const Xyzz<Q>*)st.buckets[slot] + st.B, (Xyzz<Q>*)st.partials[slot]);
     ZKT_HIP(c, hipGetLastError());
     }
-    ZKT_HIP(c, hipMemcpyAsync(st.host_result[slot], st.result[slot], sizeof(Xyzz<Q>), hipMemcpyDeviceToHost, st.side));
+    // the (ny + 1) x R2_BLOCKS partial sums go to the host, which finishes the reduction (msm_host_finish)
+    ZKT_HIP(c, hipMemcpyAsync(st.host_result[slot], st.partials[slot], (size_t)(ny + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>),
+                              hipMemcpyDeviceToHost, st.side));
     ZKT_HIP(c, hipEventRecord(st.ev_done[slot], st.side));
     st.pending[slot] = true;
     return ZKT_OK;
+}
+
+// S = sum_y 2^(e_y) V_y : V_0 = sum of segA (e = 0), V_(k+1) = sum of segT over segments with bit k (e = k + LOG_SEG),
+// the top bucket (e = c - 1).  ~150 curve operations on 64-bit limbs.
+template <class Q>
+static Xyzz<Q> msm_host_finish(const MsmState& st, int slot) {
+    const int ny = msm_rows(st.c);
+    int exps[MSM_MAX_Y + 1];
+    exps[0] = 0;
+    for (int y = 1; y < ny; ++y) exps[y] = (y - 1) + MSM_LOG_SEG;
+    exps[ny] = st.c - 1;
+    return hostec::weighted_row_sum<Q>((const Xyzz<Q>*)st.host_result[slot], ny + 1, MSM_R2_BLOCKS, exps);
 }
 
 // waits for the MSM in `slot` and normalises its result on the host (one inversion; the affine
@@ -934,9 +928,7 @@ static int msm_collect(zkt_ctx* c, int slot, Affine<typename C::Fq>* out) {
     MsmState& st = *c->msm;
     ZKT_HIP(c, hipEventSynchronize(st.ev_done[slot]));
     st.pending[slot] = false;
-    Xyzz<Q> r;
-    memcpy(&r, st.host_result[slot], sizeof(r));
-    *out = xyzz_to_affine_host<Q>(r);
+    *out = xyzz_to_affine_host<Q>(msm_host_finish<Q>(st, slot));
     return ZKT_OK;
 }
 
@@ -955,7 +947,7 @@ static int msm_collect_sharded(zkt_ctx* c, const int* slots, const bool* have, i
         if (have[j]) {
             ZKT_HIP(c, hipEventSynchronize(st.ev_done[slots[j]]));
             st.pending[slots[j]] = false;
-            memcpy(&send[j], st.host_result[slots[j]], sizeof(Xyzz<Q>));
+            send[j] = msm_host_finish<Q>(st, slots[j]);
         } else {
             send[j] = xyzz_identity<Q>();
         }
