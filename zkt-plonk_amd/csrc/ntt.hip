@@ -6,7 +6,7 @@ namespace zkt {
 
 constexpr int TILE_LOG = 10;          // elements per workgroup tile
 constexpr int TILE = 1 << TILE_LOG;   // 1024 x 32 B = 32 KiB of LDS
-constexpr int NTT_THREADS = 128;      // 8 elements per thread
+constexpr int NTT_THREADS = 256;      // 4 elements per thread
 constexpr int EPT = TILE / NTT_THREADS;
 
 // LDS tile: every element is held as nine 29-bit limbs (fx.hpp), lazily reduced (< 2p between steps),
@@ -126,24 +126,30 @@ ZKT_D void dif_step(uint4* lo, uint4* hi, uint32_t* top, const W& w_inner, int t
 template <class P, int LOG_R, class W>
 ZKT_D void dif_all(uint4* lo, uint4* hi, uint32_t* top, const W& w, int tid) {
     if constexpr (LOG_R == 5) {
-        dif_step<P, 5, 3, 0>(lo, hi, top, w, tid); __syncthreads();
-        dif_step<P, 5, 2, 3>(lo, hi, top, w, tid);
+        dif_step<P, 5, 2, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 5, 2, 2>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 5, 1, 4>(lo, hi, top, w, tid);
     } else if constexpr (LOG_R == 6) {
-        dif_step<P, 6, 3, 0>(lo, hi, top, w, tid); __syncthreads();
-        dif_step<P, 6, 3, 3>(lo, hi, top, w, tid);
+        dif_step<P, 6, 2, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 6, 2, 2>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 6, 2, 4>(lo, hi, top, w, tid);
     } else if constexpr (LOG_R == 7) {
-        dif_step<P, 7, 3, 0>(lo, hi, top, w, tid); __syncthreads();
-        dif_step<P, 7, 3, 3>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 7, 2, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 7, 2, 2>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 7, 2, 4>(lo, hi, top, w, tid); __syncthreads();
         dif_step<P, 7, 1, 6>(lo, hi, top, w, tid);
     } else if constexpr (LOG_R == 8) {
-        dif_step<P, 8, 3, 0>(lo, hi, top, w, tid); __syncthreads();
-        dif_step<P, 8, 3, 3>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 8, 2, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 8, 2, 2>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 8, 2, 4>(lo, hi, top, w, tid); __syncthreads();
         dif_step<P, 8, 2, 6>(lo, hi, top, w, tid);
     } else {
         static_assert(LOG_R == 9, "unsupported radix");
-        dif_step<P, 9, 3, 0>(lo, hi, top, w, tid); __syncthreads();
-        dif_step<P, 9, 3, 3>(lo, hi, top, w, tid); __syncthreads();
-        dif_step<P, 9, 3, 6>(lo, hi, top, w, tid);
+        dif_step<P, 9, 2, 0>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 9, 2, 2>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 9, 2, 4>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 9, 2, 6>(lo, hi, top, w, tid); __syncthreads();
+        dif_step<P, 9, 1, 8>(lo, hi, top, w, tid);
     }
 }
 
