@@ -50,7 +50,7 @@ struct MsmState {
     size_t slice_off = 0, total = 0;
     int c = 0, W = 0;      // max window bits, windows
     MsmWindows win{};
-    uint32_t* heavy = nullptr;  // [0] = count, [1..] = heavy bucket ids
+    uint32_t* heavy[11] = {};   // per slot: [0] = count, [1..] = heavy bucket ids
     uint32_t B = 0;        // buckets = 2^(c-1), ids 1..B
     void* table = nullptr; // Affine[W][count]
     // work buffers (sized for n = count)
@@ -64,16 +64,17 @@ struct MsmState {
     uint32_t nb1 = 0;                              // level-1 bins
     uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
     uint32_t l2_items = 0;                         // upper bound of level-2 tiles
-    uint32_t* offsets = nullptr;  // B + 2
-    void* pieces = nullptr;       // XyzzRaw[max_chunks + B + 2]
+    // per slot, because the bucket fold that reads them runs on the side stream while the next MSM is already grouping
+    uint32_t* offsets[11] = {};   // B + 2
+    void* pieces[11] = {};        // XyzzRaw[max_chunks + B + 2]
     // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
     // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
     static constexpr int SLOTS = 11;
     void* buckets[SLOTS] = {};      // Xyzz[B + 1]
     void* segA[SLOTS] = {};         // Xyzz[B / SEG]
     void* segT[SLOTS] = {};
-    void* partials[SLOTS] = {};     // Xyzz[MAX_Y * R2_BLOCKS]
     void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
+    void* host_result_dev[SLOTS] = {};  // the same memory as the kernels address it
     size_t acc_threads = 196608;   // resident threads of k_msm_accumulate (occupancy query at setup)
     hipStream_t side = nullptr;
     hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
@@ -711,10 +712,14 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         const int lds = (int)(2 * st->nb1 * 4 + MSM_L1_CAP * 8);
         ZKT_HIP(c, hipFuncSetAttribute((const void*)k_msm_bin_scatter<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    if ((rc = dev_alloc(c, (void**)&st->offsets, ((size_t)st->nb1 * 256 + 2) * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->heavy, ((size_t)st->B + 2) * 4))) return rc;
+    static_assert(MsmState::SLOTS == 11, "per-slot arrays are sized for 11 slots");
+    for (int i = 0; i < MsmState::SLOTS; ++i) {
+        if ((rc = dev_alloc(c, (void**)&st->offsets[i], ((size_t)st->nb1 * 256 + 2) * 4))) return rc;
+        if ((rc = dev_alloc(c, (void**)&st->heavy[i], ((size_t)st->B + 2) * 4))) return rc;
+    }
     size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
-    if ((rc = dev_alloc(c, &st->pieces, (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
+    for (int i = 0; i < MsmState::SLOTS; ++i)
+        if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
     size_t nseg = st->B / MSM_SEG;
     {
@@ -730,8 +735,8 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segA[i], nseg * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segT[i], nseg * sizeof(Xyzz<Q>)))) return rc;
-        if ((rc = dev_alloc(c, &st->partials[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)))) return rc;
-        ZKT_HIP(c, hipHostMalloc(&st->host_result[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>)));
+        ZKT_HIP(c, hipHostMalloc(&st->host_result[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>), hipHostMallocMapped));
+        ZKT_HIP(c, hipHostGetDevicePointer(&st->host_result_dev[i], st->host_result[i], 0));
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_done[i], hipEventDisableTiming));
     }
@@ -761,12 +766,12 @@ void msm_release(zkt_ctx* c) {
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
-    void* ptrs[] = {st.heavy,   st.table,     st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
-                    st.tile_start, st.cnt2,   st.pos2,  st.offsets, st.pieces, st.chunk_bucket};
+    void* ptrs[] = {st.table,     st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
+                    st.tile_start, st.cnt2,   st.pos2,  st.chunk_bucket};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
+        dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]);
         dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
-        dev_free(c, st.partials[i]);
     }
     c->msm.reset();
 }
@@ -838,6 +843,8 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     using R = typename C::Fr;
     MsmState& st = *c->msm;
     ++c->msm_epoch;   // slot buffers change hands: anything issued ahead of time that relied on them is stale
+    // the slot's buffers may still be read by the previous MSM that used this slot (side stream)
+    if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
     const uint32_t m = (uint32_t)((size_t)st.W * n);
     // one chunk per thread, and exactly as many threads as the chip keeps resident for this kernel: the
     // whole array is consumed in a single wave-front with no partially filled last round
@@ -853,7 +860,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
                            (const Fe<R>*)d_scalars, n, mont, st.win, S, st.nb1, st.bin_offs);
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
         hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
-                           st.bin_start, st.tile_start, st.heavy);
+                           st.bin_start, st.tile_start, st.heavy[slot]);
         ZKT_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 8 + (size_t)MSM_L1_CAP * 8,
                            c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S, st.count, base_off, st.nb1,
@@ -863,7 +870,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         hipLaunchKernelGGL(k_msm_l2_count, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
                            st.bin_start, st.tile_start, st.cnt2);
         hipLaunchKernelGGL(k_msm_l2_scan, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
-                           st.tile_start, st.offsets, st.B, chunk, st.chunk_bucket);
+                           st.tile_start, st.offsets[slot], st.B, chunk, st.chunk_bucket);
         hipLaunchKernelGGL(k_msm_l2_scatter, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
                            st.bin_start, st.tile_start, st.cnt2, st.pos2, st.vals2);
         ZKT_HIP(c, hipGetLastError());
@@ -872,21 +879,23 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + chunk - 1) / chunk;
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.vals2,
-                           st.B, chunk, st.offsets, st.chunk_bucket, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces);
+                           st.B, chunk, st.offsets[slot], st.chunk_bucket, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces[slot]);
         ZKT_HIP(c, hipGetLastError());
     }
-    // the slot's tail buffers may still be read by the previous MSM that used this slot
-    if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
-    hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, c->stream, st.offsets, st.B,
-                       chunk, (const XyzzRaw<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
-    ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, c->stream, st.offsets, chunk,
-                       (const XyzzRaw<Q>*)st.pieces, (Xyzz<Q>*)st.buckets[slot], st.heavy);
-    ZKT_HIP(c, hipGetLastError());
     }
-    // ---- tail on the side stream: overlaps whatever the main stream does next ----
+    // ---- tail on the side stream: the bucket fold (latency bound: one wave per SIMD, three dependent additions) and the
+    // bucket reduction overlap whatever the main stream does next; everything they read is the slot's own ----
     ZKT_HIP(c, hipEventRecord(st.ev_main[slot], c->stream));
     ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[slot], 0));
+    {
+    ProfScope prof_fold(c, "msm_fold", st.side);
+    hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, st.side, st.offsets[slot], st.B,
+                       chunk, (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
+    ZKT_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, st.side, st.offsets[slot], chunk,
+                       (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
+    ZKT_HIP(c, hipGetLastError());
+    }
     int ny = 0;
     {
     ProfScope prof_tail(c, "msm_tail", st.side);
@@ -897,12 +906,11 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     ny = msm_rows(st.c);
     hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny + 1), dim3(256), 0, st.side,
                        (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], nseg, ny,
-                       (const Xyzz<Q>*)st.buckets[slot] + st.B, (Xyzz<Q>*)st.partials[slot]);
+                       (const Xyzz<Q>*)st.buckets[slot] + st.B, (Xyzz<Q>*)st.host_result_dev[slot]);
     ZKT_HIP(c, hipGetLastError());
     }
-    // the (ny + 1) x R2_BLOCKS partial sums go to the host, which finishes the reduction (msm_host_finish)
-    ZKT_HIP(c, hipMemcpyAsync(st.host_result[slot], st.partials[slot], (size_t)(ny + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>),
-                              hipMemcpyDeviceToHost, st.side));
+    // the (ny + 1) x R2_BLOCKS partial sums are written straight into pinned host memory (129 posted writes of 128 B;
+    // a copy engine took ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
     ZKT_HIP(c, hipEventRecord(st.ev_done[slot], st.side));
     st.pending[slot] = true;
     return ZKT_OK;
