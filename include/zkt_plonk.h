@@ -263,6 +263,29 @@ int zkt_prove_set_next(zkt_ctx* ctx, const zkt_prove_inputs* next);
 int zkt_prove_with(zkt_ctx* ctx, const zkt_prove_inputs* in, const zkt_transcript_vtable* transcript,
                    uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 
+/* ---- Verifier, everything but the pairings (proof_system/proof.rs:285-503) ------------------------
+ * Deserialises the proof (proof.rs:98-155; points are decompressed and checked to be on the curve), replays the
+ * transcript, computes r0 (proof.rs:163-217) and the linearisation commitment (proof.rs:220-282, the 13-point
+ * multi_scalar_mul of commitment.rs:32-45), and folds each of the two SonicKZG10::check calls (proof.rs:420-500) into
+ * ONE pair of G1 points (L, W) with L = sum_i eta^i C_i - (sum_i eta^i v_i) g + z W: the opening is valid iff
+ * e(L, h) == e(W, beta h).  The two pairings stay with the caller (arkworks), who holds h and beta h.  Host-only code:
+ * a proof is ~30 short scalar multiplications.  `transcript` must be seeded like the prover's.
+ * out_pairs: L1, W1, L2, W2 as (x, y) Montgomery limbs; out_is_infinity: 4 flags (may be NULL).
+ * Errors: ZKT_ERR_INVALID_ARGUMENT for malformed bytes / points off the curve, ZKT_ERR_EQUAL_CHALLENGES (proof.rs:340-345). */
+typedef struct {
+    uint64_t n;                         /* VerifierKey::n */
+    const uint64_t* vk_commitments;     /* 10 x (x, y), zkt_transcript_seed order */
+    const int* vk_is_infinity;          /* 10 flags or NULL */
+    const uint64_t* pi_roots;           /* VerifierKey::pi_roots, n_pi Montgomery scalars */
+    const uint64_t* pub_inputs;         /* the public inputs, same order */
+    size_t n_pi;
+    const uint8_t* proof;               /* CanonicalSerialize bytes (802 / 1010) */
+    size_t proof_len;
+    const uint64_t* g;                  /* SonicKZG10 VerifierKey::g (= powers_of_g[0]), (x, y) */
+} zkt_verify_inputs;
+int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, uint64_t* out_pairs,
+                       int* out_is_infinity);
+
 /* ---- key files of the reference CLI ------------------------------------------------------------
  * `serialize_to_file` = CanonicalSerialize::serialize_unchecked (bin/src/parser.rs:14-22).  Layouts restated from
  * ark-serialize / ark-poly-commit 0.3 (see csrc/keyfile.hip); the reference holds no key file, so these readers are

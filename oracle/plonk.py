@@ -742,8 +742,10 @@ def kzg_check_with_trapdoor(cv: Curve, tau: int, commits: Sequence[Point], point
     return lhs == rhs
 
 
-def verify(cv: Curve, tau: int, vk: VerifierKey, proof: Proof, transcript, pub_inputs: Sequence[int]) -> bool:
-    """proof_system/proof.rs:285-503 (compute_r0 163-217, compute_linearization_commitment 220-282)."""
+def verify_prepare(cv: Curve, vk: VerifierKey, proof: Proof, transcript, pub_inputs: Sequence[int]):
+    """proof_system/proof.rs:285-503 up to (not including) the two pairing checks of SonicKZG10::check: returns
+    [(L1, W1), (L2, W2)] with L = sum_i eta^i C_i - (sum_i eta^i v_i) G + z W, so that the KZG check of each opening is
+    e(L, h) == e(W, beta h)  (compute_r0 163-217, compute_linearization_commitment 220-282)."""
     p = cv.fr.p
     dom = Domain(cv.fr, vk.n)
     assert len(pub_inputs) == len(vk.pi_roots)
@@ -800,14 +802,27 @@ def verify(cv: Curve, tau: int, vk: VerifierKey, proof: Proof, transcript, pub_i
                       ("h1_next_eval", "h1_next"), ("h2_eval", "h2")):
         transcript.append_scalar(name, getattr(ev, key))
     eta = transcript.challenge_scalar("eta")
-    ok1 = kzg_check_with_trapdoor(
-        cv, tau, [r_commit, cm["a"], cm["b"], cm["c"], V["sigma1"], V["sigma2"], V["q_lookup"], cm["t"], cm["h2"]],
-        xi, [r0, ev.a, ev.b, ev.c, ev.sigma1, ev.sigma2, ev.q_lookup, ev.t, ev.h2], proof.aw_opening, eta)
-    if not ok1:
-        return False
-    return kzg_check_with_trapdoor(
-        cv, tau, [cm["z1"], cm["z2"], cm["t"], cm["h1"]], xi * dom.group_gen % p,
-        [ev.z1_next, ev.z2_next, ev.t_next, ev.h1_next], proof.saw_opening, eta)
+
+    def pair(commits, point, values, w):
+        comb_c: Point = None
+        comb_v, ch = 0, 1
+        for c_, v in zip(commits, values):
+            comb_c = C.add(cv, comb_c, C.scalar_mul(cv, ch, c_))
+            comb_v = (comb_v + ch * v) % p
+            ch = ch * eta % p
+        lhs = C.add(cv, comb_c, C.neg(cv, C.scalar_mul(cv, comb_v, C.generator(cv))))
+        return C.add(cv, lhs, C.scalar_mul(cv, point % p, w)), w
+
+    return [pair([r_commit, cm["a"], cm["b"], cm["c"], V["sigma1"], V["sigma2"], V["q_lookup"], cm["t"], cm["h2"]], xi,
+                 [r0, ev.a, ev.b, ev.c, ev.sigma1, ev.sigma2, ev.q_lookup, ev.t, ev.h2], proof.aw_opening),
+            pair([cm["z1"], cm["z2"], cm["t"], cm["h1"]], xi * dom.group_gen % p,
+                 [ev.z1_next, ev.z2_next, ev.t_next, ev.h1_next], proof.saw_opening)]
+
+
+def verify(cv: Curve, tau: int, vk: VerifierKey, proof: Proof, transcript, pub_inputs: Sequence[int]) -> bool:
+    """proof_system/proof.rs:285-503 with the pairing check e(L, h) == e(W, tau h) of each opening replaced by the
+    equivalent G1 identity under the known test trapdoor: L == tau W."""
+    return all(L == C.scalar_mul(cv, tau % cv.fr.p, W) for L, W in verify_prepare(cv, vk, proof, transcript, pub_inputs))
 
 
 def new_seeded_transcript(cv: Curve, vk: VerifierKey, kind: str = "merlin"):

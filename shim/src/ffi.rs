@@ -1,0 +1,72 @@
+//! Raw declarations of include/zkt_plonk.h (the subset the shim uses).  Field elements cross as arkworks'
+//! in-memory Montgomery limbs (`Fp256` = `BigInteger256([u64; 4])`), points as x limbs || y limbs, (0, 0) = infinity.
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct ZktCtx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct ZktTranscriptVtable {
+    pub user: *mut c_void,
+    pub append_u64: extern "C" fn(*mut c_void, *const c_char, u64),
+    pub append_scalars: extern "C" fn(*mut c_void, *const c_char, *const u64, usize, c_int),
+    pub append_commitment: extern "C" fn(*mut c_void, *const c_char, *const u64, c_int),
+    pub challenge_scalar: extern "C" fn(*mut c_void, *const c_char, *mut u64),
+}
+
+#[repr(C)]
+pub struct ZktCommVtable {
+    pub user: *mut c_void,
+    pub rank: c_int,
+    pub world: c_int,
+    pub device_buffers: c_int,
+    pub all_gather: extern "C" fn(*mut c_void, *const c_void, *mut c_void, usize, c_int, *mut c_void) -> c_int,
+}
+
+#[repr(C)]
+pub struct ZktProveInputs {
+    pub a_evals: *const u64,
+    pub b_evals: *const u64,
+    pub c_evals: *const u64,
+    pub n_rows: usize,
+    pub table: *const u64,
+    pub table_len: usize,
+    pub pi_pos: *const usize,
+    pub pi_vals: *const u64,
+    pub n_pi: usize,
+    pub blinders: *const u64,
+    pub wires_on_device: c_int,
+    pub variables: *const u64,
+    pub n_vars: usize,
+    pub w_l: *const u32,
+    pub w_r: *const u32,
+    pub w_o: *const u32,
+}
+
+pub const ZKT_VARIABLE_ZERO: u32 = 0xFFFF_FFFF;
+pub const ZKT_CURVE_BN254: c_int = 0;
+pub const ZKT_CURVE_BLS12_381: c_int = 1;
+
+extern "C" {
+    pub fn zkt_ctx_create(curve_id: c_int, device_id: c_int, out: *mut *mut ZktCtx) -> c_int;
+    pub fn zkt_ctx_destroy(ctx: *mut ZktCtx);
+    pub fn zkt_last_error(ctx: *const ZktCtx) -> *const c_char;
+    pub fn zkt_ctx_set_comm(ctx: *mut ZktCtx, comm: *const ZktCommVtable) -> c_int;
+    pub fn zkt_shard_range(total: usize, rank: c_int, world: c_int, lo: *mut usize, hi: *mut usize) -> c_int;
+    pub fn zkt_ntt(ctx: *mut ZktCtx, log_n: c_int, inverse: c_int, coset: c_int, input: *const u64, in_len: usize,
+                   out: *mut u64) -> c_int;
+    pub fn zkt_srs_load(ctx: *mut ZktCtx, g1_xy_mont: *const u64, count: usize) -> c_int;
+    pub fn zkt_srs_load_slice(ctx: *mut ZktCtx, g1_xy_mont: *const u64, offset: usize, count: usize, total: usize) -> c_int;
+    pub fn zkt_srs_load_file(ctx: *mut ZktCtx, ck_path: *const c_char, max_powers: usize) -> c_int;
+    pub fn zkt_msm_g1(ctx: *mut ZktCtx, scalars: *const u64, len: usize, base_offset: usize, scalars_montgomery: c_int,
+                      out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
+    pub fn zkt_circuit_load(ctx: *mut ZktCtx, log_n: c_int, pk_polys: *const *const u64, pk_lens: *const usize) -> c_int;
+    pub fn zkt_circuit_load_file(ctx: *mut ZktCtx, pk_path: *const c_char, log_n: c_int) -> c_int;
+    pub fn zkt_circuit_setup(ctx: *mut ZktCtx, log_n: c_int, evals: *const *const u64, eval_lens: *const usize,
+                             evals_on_device: c_int, out_commitments: *mut u64, out_is_infinity: *mut c_int) -> c_int;
+    pub fn zkt_prove_with(ctx: *mut ZktCtx, inputs: *const ZktProveInputs, transcript: *const ZktTranscriptVtable,
+                          proof_out: *mut u8, proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn zkt_prove_set_next(ctx: *mut ZktCtx, next: *const ZktProveInputs) -> c_int;
+}

@@ -1,0 +1,93 @@
+//! `zkt-plonk-gpu`: the two generic seams of `ZKTPlonk<F, D, PC, T, C, TABLE_SIZE>` (plonk-core/src/plonk.rs:39-52)
+//! bound to the MI355X library.  SOURCE ONLY -- never compiled in the authoring image (no Rust toolchain); the
+//! C-ABI underneath is what the parity tests exercise.  INTEGRATION.md walks through the pieces.
+pub mod ffi;
+
+use ark_ff::{FftField, PrimeField};
+use ark_poly::{domain::DomainCoeff, EvaluationDomain, Radix2EvaluationDomain};
+use std::cell::RefCell;
+use std::ffi::CStr;
+use std::os::raw::c_int;
+
+thread_local! {
+    // one context per proving thread (`prove` is !Send: Rc<ExtendedProverKey>, prove.rs:62)
+    static CTX: RefCell<Option<*mut ffi::ZktCtx>> = RefCell::new(None);
+}
+
+/// Maps the scalar field to the library's curve id by its modulus size / two-adicity.
+fn curve_of<F: PrimeField + FftField>() -> c_int {
+    if F::size_in_bits() == 254 { ffi::ZKT_CURVE_BN254 } else { ffi::ZKT_CURVE_BLS12_381 }
+}
+
+pub fn with_ctx<F: PrimeField + FftField, R>(f: impl FnOnce(*mut ffi::ZktCtx) -> R) -> R {
+    CTX.with(|slot| {
+        let mut slot = slot.borrow_mut();
+        if slot.is_none() {
+            let mut ctx = std::ptr::null_mut();
+            let rc = unsafe { ffi::zkt_ctx_create(curve_of::<F>(), 0, &mut ctx) };
+            assert_eq!(rc, 0, "zkt_ctx_create failed: no MI355X visible (there is no CPU fallback)");
+            *slot = Some(ctx);
+        }
+        f(slot.unwrap())
+    })
+}
+
+pub fn check(ctx: *mut ffi::ZktCtx, rc: c_int) -> Result<(), plonk_core::error::Error> {
+    if rc == 0 {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(ffi::zkt_last_error(ctx)) }.to_string_lossy().into_owned();
+    Err(match rc {
+        2 => plonk_core::error::Error::InvalidEvalDomainSize { log_size_of_group: 0, adicity: 0 },
+        8 => plonk_core::error::Error::ElementNotIndexedInTable,
+        _ => plonk_core::error::Error::PCError { error: msg },
+    })
+}
+
+/// `D: EvaluationDomain<F> + EvaluationDomainExt<F>` (prove.rs:70, util.rs:27-59): constants stay arkworks', the four
+/// transforms of util.rs:63-140 run on the GPU.
+#[derive(Copy, Clone, Hash, Eq, PartialEq, Debug)]
+pub struct GpuDomain<F: FftField> {
+    pub inner: Radix2EvaluationDomain<F>,
+}
+
+impl<F: FftField + PrimeField> GpuDomain<F> {
+    pub fn new(n: usize) -> Option<Self> {
+        Radix2EvaluationDomain::new(n).map(|inner| Self { inner })
+    }
+
+    /// inverse / coset as in include/zkt_plonk.h zkt_ntt; ark-poly resizes to n, the library zero-pads
+    pub fn run<T: DomainCoeff<F>>(&self, v: &mut Vec<T>, inverse: c_int, coset: c_int) {
+        let n = self.inner.size();
+        let in_len = v.len();
+        v.resize(n, T::zero());
+        with_ctx::<F, _>(|ctx| unsafe {
+            let rc = ffi::zkt_ntt(ctx, self.inner.log_size_of_group as c_int, inverse, coset,
+                                  v.as_ptr() as *const u64, in_len, v.as_mut_ptr() as *mut u64);
+            check(ctx, rc).expect("zkt_ntt");
+        });
+    }
+    pub fn fft_in_place<T: DomainCoeff<F>>(&self, c: &mut Vec<T>) { self.run(c, 0, 0) }         // util.rs:104-113
+    pub fn ifft_in_place<T: DomainCoeff<F>>(&self, e: &mut Vec<T>) { self.run(e, 1, 0) }        // util.rs:63-86
+    pub fn coset_fft_in_place<T: DomainCoeff<F>>(&self, c: &mut Vec<T>) { self.run(c, 0, 1) }   // util.rs:117-140
+    pub fn coset_ifft_in_place<T: DomainCoeff<F>>(&self, e: &mut Vec<T>) { self.run(e, 1, 1) }  // util.rs:90-100
+    pub fn log_size_of_group(&self) -> u32 { self.inner.log_size_of_group }                     // util.rs:52-58
+    pub fn group_gen(&self) -> F { self.inner.group_gen }
+}
+
+/// Repacks `GroupAffine { x, y, infinity }` (repr(Rust)) into x limbs || y limbs, (0, 0) for the identity.
+pub fn pack_g1<G: ark_ec::AffineCurve>(pts: &[G], limbs: usize, xy: impl Fn(&G) -> (Vec<u64>, Vec<u64>)) -> Vec<u64> {
+    let mut out = vec![0u64; pts.len() * 2 * limbs];
+    for (i, p) in pts.iter().enumerate() {
+        if p.is_zero() { continue; }
+        let (x, y) = xy(p);
+        out[2 * limbs * i..2 * limbs * i + limbs].copy_from_slice(&x);
+        out[2 * limbs * i + limbs..2 * limbs * (i + 1)].copy_from_slice(&y);
+    }
+    out
+}
+
+/// The callback table of `zkt_prove_with` over any `T: TranscriptProtocol<F, PC::Commitment>` and the call that
+/// replaces the body of `proof_system::prove` are spelled out in INTEGRATION.md section 3; they need plonk-core's
+/// crate-private `ProvingComposer`, so they live inside plonk-core under `cfg(feature = "gpu")` rather than here.
+pub mod prover {}

@@ -650,3 +650,27 @@ def test_prove_from_the_reference_cli_key_files(cv, ctxs, tmp_path):
     got = ctx.prove(K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table), pos,
                     K.fr_to_mont(cv, [cs.pi[i] for i in pos]), K.fr_to_mont(cv, blinders), tr)
     assert got == want
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_gpu_proof_through_the_product_verifier(cv, ctxs):
+    """Prover and verifier of the same library: a GPU proof goes through zkt_verify_prepare (proof.rs:285-503 without
+    the pairings) and the resulting pairs satisfy L == tau W under the test trapdoor, i.e. e(L, h) == e(W, tau h)."""
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd import _lib
+    from oracle import curve as C
+    cs = P.synthetic_circuit(cv, 2000, 64, seed=808)
+    n = cs.circuit_bound()
+    tau = 0x1234567
+    srs_arr = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    proof = _gpu_prove(z, ctxs[cv.name], cv, cs, pk, vk, srs_arr, field_elems(cv.fr.p, 5, P.NUM_BLINDERS))
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+    z.seed_transcript(tr, vk.n, vk.commits)
+    pairs, inf = _lib.verify_prepare(cv.name, vk.n, K.points_to_mont(cv, [vk.commits[k] for k in z.PK_ORDER]),
+                                     [vk.commits[k] is None for k in z.PK_ORDER], K.fr_to_mont(cv, vk.pi_roots),
+                                     K.fr_to_mont(cv, pis), proof, srs_arr[0], tr)
+    pts = [None if inf[i] else K.points_from_mont(cv, pairs[i:i + 1])[0] for i in range(4)]
+    assert pts[0] == C.scalar_mul(cv, tau, pts[1]) and pts[2] == C.scalar_mul(cv, tau, pts[3])

@@ -1,0 +1,81 @@
+"""f4: the verifier without its pairings (zkt_verify_prepare, host-only C++) against the oracle's
+restatement of proof_system/proof.rs:285-503 -- same (L, W) pairs, and the trapdoor form of the pairing check
+(L == tau W) accepts honest proofs and rejects tampered ones.  Merlin and Ethereum transcripts, both curves."""
+import numpy as np
+import pytest
+
+from oracle import fields as F, plonk as P, coracle as K, curve as C
+from helpers import field_elems
+import zkt_plonk_amd as z
+from zkt_plonk_amd import _lib
+
+
+def _proof(cv, kind, gates=150, n_public=3, seed=5):
+    cs = P.synthetic_circuit(cv, gates, 16, seed=seed, n_public=n_public)
+    n = cs.circuit_bound()
+    tau = 0x7E57ED + seed
+    srs = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    proof = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk, kind),
+                    field_elems(cv.fr.p, 70 + seed, P.NUM_BLINDERS))
+    return cs, tau, srs, vk, proof
+
+
+def _prepare(cv, kind, vk, srs, pis, proof_bytes):
+    tr = z.Transcript(kind, "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+    z.seed_transcript(tr, vk.n, vk.commits)
+    names = z.PK_ORDER
+    commits = K.points_to_mont(cv, [vk.commits[k] for k in names])
+    inf = [vk.commits[k] is None for k in names]
+    return _lib.verify_prepare(cv.name, vk.n, commits, inf, K.fr_to_mont(cv, vk.pi_roots) if pis else np.zeros((0, 4), np.uint64),
+                               K.fr_to_mont(cv, pis) if pis else np.zeros((0, 4), np.uint64), proof_bytes, srs[0], tr)
+
+
+@pytest.mark.parametrize("cv,kind", [(F.BN254, "merlin"), (F.BLS12_381, "merlin"), (F.BN254, "ethereum")],
+                         ids=["bn254-merlin", "bls12_381-merlin", "bn254-ethereum"])
+def test_verify_prepare_matches_the_oracle_and_the_trapdoor_check(cv, kind):
+    cs, tau, srs, vk, proof = _proof(cv, kind)
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    raw = proof.serialize(cv)
+    want = P.verify_prepare(cv, vk, P.proof_deserialize(cv, raw), P.new_seeded_transcript(cv, vk, kind), pis)
+    got, inf = _prepare(cv, kind, vk, srs, pis, raw)
+    pts = [None if inf[i] else K.points_from_mont(cv, got[i:i + 1])[0] for i in range(4)]
+    assert [(pts[0], pts[1]), (pts[2], pts[3])] == want
+    for L, W in ((pts[0], pts[1]), (pts[2], pts[3])):
+        assert L == C.scalar_mul(cv, tau, W)                        # e(L, h) == e(W, tau h)
+    # a flipped evaluation, a swapped commitment and a wrong public input are all rejected by the same identity
+    bad = bytearray(raw)
+    bad[-40] ^= 1
+    nb = (cv.fq.bits + 2 + 7) // 8
+    swapped = raw[nb:2 * nb] + raw[:nb] + raw[2 * nb:]
+    for tampered, tp in ((bytes(bad), pis), (swapped, pis), (raw, [(pis[0] + 1) % cv.fr.p] + pis[1:])):
+        g2, i2 = _prepare(cv, kind, vk, srs, tp, tampered)
+        p2 = [None if i2[i] else K.points_from_mont(cv, g2[i:i + 1])[0] for i in range(4)]
+        assert not (p2[0] == C.scalar_mul(cv, tau, p2[1]) and p2[2] == C.scalar_mul(cv, tau, p2[3]))
+
+
+def test_verify_prepare_rejects_malformed_proofs():
+    cv = F.BN254
+    cs, tau, srs, vk, proof = _proof(cv, "merlin", seed=9)
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    raw = proof.serialize(cv)
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, raw[:-1])                          # wrong length
+    off = bytearray(raw)
+    x = int.from_bytes(raw[:31], "little")
+    for delta in range(1, 50):                                                  # an x with no point above it
+        cand = (x + delta) % cv.fq.p
+        if pow((cand ** 3 + cv.b) % cv.fq.p, (cv.fq.p - 1) // 2, cv.fq.p) != 1:
+            off[:32] = cand.to_bytes(32, "little")
+            break
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, bytes(off))
+    nonc = bytearray(raw)
+    nonc[-32:] = (cv.fr.p).to_bytes(32, "little")                               # evaluation = modulus: not canonical
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, bytes(nonc))
+    some = bytearray(raw)
+    some[11 * 32 + 32] = 1                                                      # kzg10::Proof::random_v must be None
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, bytes(some))

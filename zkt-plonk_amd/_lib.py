@@ -179,6 +179,39 @@ def keyfile_verifier_key(path: str, curve):
     return n.value, roots[:k.value], commits, np.array([bool(x) for x in inf])
 
 
+class VerifyInputs(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("vk_commitments", ctypes.POINTER(ctypes.c_uint64)),
+                ("vk_is_infinity", ctypes.POINTER(ctypes.c_int)), ("pi_roots", ctypes.POINTER(ctypes.c_uint64)),
+                ("pub_inputs", ctypes.POINTER(ctypes.c_uint64)), ("n_pi", ctypes.c_size_t),
+                ("proof", ctypes.c_char_p), ("proof_len", ctypes.c_size_t), ("g", ctypes.POINTER(ctypes.c_uint64))]
+
+
+def verify_prepare(curve, n: int, vk_commits: np.ndarray, vk_inf, pi_roots: np.ndarray, pub_inputs: np.ndarray, proof: bytes,
+                   g_xy: np.ndarray, transcript):
+    """proof_system/proof.rs:285-503 without the pairings (zkt_verify_prepare; host only).  Arrays are Montgomery limbs;
+    `transcript` is a seeded Transcript.  -> (pairs (4, 2*fq_limbs) = L1, W1, L2, W2; is_infinity (4,))."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    vk_commits = np.ascontiguousarray(vk_commits, dtype=np.uint64).reshape(10, words)
+    pi_roots = np.ascontiguousarray(pi_roots, dtype=np.uint64).reshape(-1, 4)
+    pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1, 4)
+    assert pi_roots.shape == pub_inputs.shape
+    g_xy = np.ascontiguousarray(g_xy, dtype=np.uint64).reshape(words)
+    inf = (ctypes.c_int * 10)(*[int(bool(x)) for x in vk_inf])
+    null = ctypes.POINTER(ctypes.c_uint64)()
+    inp = VerifyInputs(n, u64p(vk_commits), inf, u64p(pi_roots) if pi_roots.size else null,
+                       u64p(pub_inputs) if pub_inputs.size else null, pi_roots.shape[0], proof, len(proof), u64p(g_xy))
+    out = np.zeros((4, words), dtype=np.uint64)
+    oinf = (ctypes.c_int * 4)()
+    L.zkt_verify_prepare.argtypes = [ctypes.c_int, ctypes.POINTER(VerifyInputs), ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+    rc = L.zkt_verify_prepare(cid, ctypes.byref(inp), transcript.handle, u64p(out), oinf)
+    if rc:
+        raise ZktError(rc, "zkt_verify_prepare")
+    return out, np.array([bool(x) for x in oinf])
+
+
 class ProveInputs(ctypes.Structure):
     _fields_ = [("a_evals", ctypes.POINTER(ctypes.c_uint64)), ("b_evals", ctypes.POINTER(ctypes.c_uint64)),
                 ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),

@@ -17,11 +17,13 @@ struct Bn254Curve {
     using Fq = Bn254Fq;
     using Fr = Bn254Fr;
     static constexpr int ID = 0;
+    static constexpr uint32_t B = 3;   // y^2 = x^3 + 3
 };
 struct Bls381Curve {
     using Fq = Bls381Fq;
     using Fr = Bls381Fr;
     static constexpr int ID = 1;
+    static constexpr uint32_t B = 4;   // y^2 = x^3 + 4
 };
 
 template <class Q>

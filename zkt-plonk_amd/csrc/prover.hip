@@ -971,11 +971,6 @@ struct VtableTranscript;  // capi glue below
 
 using namespace zkt;
 
-struct zkt_transcript {
-    std::unique_ptr<HostTranscript> impl;
-    Merlin* merlin = nullptr;  // raw access for the conformance KAT
-};
-
 namespace zkt {
 // Adapter over a foreign transcript (the Rust shim's `T: TranscriptProtocol`): values cross in
 // arkworks' Montgomery limbs, exactly what the shim can hand to T::append_scalar / append_commitment.

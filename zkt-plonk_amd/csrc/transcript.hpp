@@ -83,3 +83,10 @@ struct EthereumHostTranscript : HostTranscript {
 };
 
 }  // namespace zkt
+
+#include <memory>
+// the opaque handle of include/zkt_plonk.h
+struct zkt_transcript {
+    std::unique_ptr<zkt::HostTranscript> impl;
+    zkt::Merlin* merlin = nullptr;  // raw access for the conformance KAT
+};
