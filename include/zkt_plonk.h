@@ -263,6 +263,23 @@ int zkt_prove_set_next(zkt_ctx* ctx, const zkt_prove_inputs* next);
 int zkt_prove_with(zkt_ctx* ctx, const zkt_prove_inputs* in, const zkt_transcript_vtable* transcript,
                    uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 
+/* ---- Witness synthesis for Poseidon-heavy circuits as a batched field kernel ---------------------
+ * The permutation of plonk-hashing/src/hasher/poseidon/spec.rs (rounds :18-111, schedule :267-316, input layout
+ * :239-265: state[0] = domain_tag, the inputs follow, output = state[1]) for `batch` independent hashes, one thread per
+ * hash; out_states (optional) receives every round's state, batch x (rounds + 1) x width scalars, i.e. the values a
+ * composer assigns to the variables of its Poseidon gates.  Constants are the caller's PoseidonConstants (the
+ * reference generates them at run time, constants.rs:27).  Everything in Montgomery limbs; host pointers. */
+typedef struct {
+    int width;                       /* 2 .. 8 */
+    int half_full_rounds;            /* full rounds before and after the partial ones */
+    int partial_rounds;
+    const uint64_t* round_constants; /* (2 half_full + partial) x width */
+    const uint64_t* mds;             /* width x width, row major: m[i][j] */
+    const uint64_t* domain_tag;      /* one scalar */
+} zkt_poseidon_params;
+int zkt_poseidon_hash_batch(zkt_ctx* ctx, const zkt_poseidon_params* params, const uint64_t* inputs, size_t batch, int arity,
+                            uint64_t* out_hashes, uint64_t* out_states);
+
 /* ---- Verifier, everything but the pairings (proof_system/proof.rs:285-503) ------------------------
  * Deserialises the proof (proof.rs:98-155; points are decompressed and checked to be on the curve), replays the
  * transcript, computes r0 (proof.rs:163-217) and the linearisation commitment (proof.rs:220-282, the 13-point

@@ -431,6 +431,32 @@ class Context:
         self.check(L.zkt_ntt_class(self._h, log_n, log_big, cls, u64p(arr), arr.shape[0], u64p(out)))
         return out
 
+    # -- batched Poseidon (witness synthesis) ------------------------------------------------------------
+    def poseidon_hash_batch(self, width, half_full, partial, round_constants, mds, domain_tag, inputs, trace=False):
+        """plonk-hashing's Poseidon permutation for a batch of inputs ((batch, arity, 4) Montgomery limbs) ->
+        hashes (batch, 4) [, states (batch, rounds + 1, width, 4)]."""
+        class Params(ctypes.Structure):
+            _fields_ = [("width", ctypes.c_int), ("half_full_rounds", ctypes.c_int), ("partial_rounds", ctypes.c_int),
+                        ("round_constants", ctypes.POINTER(ctypes.c_uint64)), ("mds", ctypes.POINTER(ctypes.c_uint64)),
+                        ("domain_tag", ctypes.POINTER(ctypes.c_uint64))]
+        rc = np.ascontiguousarray(round_constants, dtype=np.uint64).reshape(-1, 4)
+        m = np.ascontiguousarray(mds, dtype=np.uint64).reshape(width * width, 4)
+        tag = np.ascontiguousarray(domain_tag, dtype=np.uint64).reshape(4)
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        batch, arity = inp.shape[0], (inp.shape[1] if inp.ndim == 3 else 0)
+        rounds = 2 * half_full + partial
+        assert rc.shape[0] == rounds * width
+        out = np.zeros((batch, 4), dtype=np.uint64)
+        st = np.zeros((batch, rounds + 1, width, 4), dtype=np.uint64) if trace else None
+        prm = Params(width, half_full, partial, u64p(rc), u64p(m), u64p(tag))
+        L = self._L
+        L.zkt_poseidon_hash_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.POINTER(ctypes.c_uint64),
+                                              ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                                              ctypes.POINTER(ctypes.c_uint64)]
+        self.check(L.zkt_poseidon_hash_batch(self._h, ctypes.byref(prm), u64p(inp.reshape(-1, 4)) if inp.size else None, batch,
+                                             arity, u64p(out), u64p(st.reshape(-1, 4)) if trace else None))
+        return (out, st) if trace else out
+
     # -- device memory ------------------------------------------------------------------------
     def alloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()
