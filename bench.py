@@ -3,7 +3,7 @@
 
 A "step" is one full pass of proof_system::prove (plonk-core/src/proof_system/prove.rs:59-470) over one
 batch of synthetic witness rows already resident in HBM: iNTT(n) of every witness polynomial, their
-coset NTT(4n), the fused quotient pass, two grand products, the KZG commitments (MSMs of ~n points),
+coset NTT(4n), the fused quotient pass, two grand products, the 12-13 KZG commitments (MSMs of ~n points),
 the 12 evaluations and the two openings, with Fiat-Shamir (Merlin) on the host.  Default workload:
 BASELINE.json configs[3] shape -- BN254, n = 2^20 rows, TABLE_SIZE = 1024, 7 public inputs.
 

@@ -2,9 +2,12 @@
 
 Host-side mirror of the reference's two generic seams:
 
-* ``GpuDomain``  ~ ``D: EvaluationDomain<F> + EvaluationDomainExt<F>``  (plonk-core/src/util.rs:27-140)
-* ``GpuKZG10``   ~ ``PC: HomomorphicCommitment<F>`` = SonicKZG10 commit/open (plonk-core/src/commitment.rs:24-46)
-* ``prove``      ~ ``proof_system::prove``                                 (plonk-core/src/proof_system/prove.rs:59-470)
+* ``GpuDomain``        ~ ``D: EvaluationDomain<F> + EvaluationDomainExt<F>``  (plonk-core/src/util.rs:27-140)
+* ``Context.msm``      ~ ``PC::commit`` = kzg10 commit = G1 MSM over the loaded powers (plonk-core/src/commitment.rs:24-46)
+* ``GpuProver.prove``  ~ ``proof_system::prove``  (plonk-core/src/proof_system/prove.rs:59-470; the openings live inside it)
+* ``parallel``         ~ one proof or many across the GPUs of a node (communicators, SRS slices)
+
+These are thin ctypes mirrors for the tests and ``bench.py``; the product is the C-ABI (include/zkt_plonk.h).
 
 All numerics run in ``libzkt_plonk_hip.so`` (hand-written HIP kernels).  There is no CPU fallback:
 importing works without a GPU (so the C-ABI can be inspected), creating a ``Context`` does not.
