@@ -41,11 +41,11 @@ for w in range(F):
     pi_vals = B.fr_to_mont_gpu(ctx, fld, [circ["pi"][k] for k in pi_pos])
     rnd = random.Random(99)
     blinders = B.fr_to_mont_gpu(ctx, fld, [rnd.randrange(fld["r"]) for _ in range(z.NUM_BLINDERS)])
-    def one(ctx=ctx, wires=wires, table=table, pi_vals=pi_vals, blinders=blinders, vk=vk):
+    prep = ctx.prepare_dev(wires[0].data_ptr(), wires[1].data_ptr(), wires[2].data_ptr(), gates, table, pi_pos, pi_vals, blinders)
+    def one(ctx=ctx, prep=prep, vk=vk, _keep=wires):   # the prepared inputs point into these tensors
         tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=fld["lam"], fq_bytes=8 * L)
         z.seed_transcript(tr, n, vk)
-        return ctx.prove_dev(wires[0].data_ptr(), wires[1].data_ptr(), wires[2].data_ptr(), gates, table, pi_pos,
-                             pi_vals, blinders, tr)
+        return ctx.prove_prepared(prep, tr, prep)      # chained: every proof announces the next one
     workers.append((ctx, prover, one))
 proofs = [None] * F
 def run(w, k):
