@@ -303,6 +303,12 @@ typedef struct {
 int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, uint64_t* out_pairs,
                        int* out_is_infinity);
 
+/* HomomorphicCommitment::multi_scalar_mul (commitment.rs:32-45) for ARBITRARY points: the verifier's 13-point
+ * linearisation commitment and similar short combinations.  Host arithmetic (double-and-add on 64-bit limbs): at this
+ * size a device launch would cost more than the sum.  scalars: 4 limbs each, Montgomery or canonical. */
+int zkt_g1_msm_host(int curve_id, const uint64_t* points_xy_mont, const uint64_t* scalars, size_t n, int scalars_montgomery,
+                    uint64_t* out_xy_mont, int* out_is_infinity);
+
 /* ---- key files of the reference CLI ------------------------------------------------------------
  * `serialize_to_file` = CanonicalSerialize::serialize_unchecked (bin/src/parser.rs:14-22).  Layouts restated from
  * ark-serialize / ark-poly-commit 0.3 (see csrc/keyfile.hip); the reference holds no key file, so these readers are

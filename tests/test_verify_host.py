@@ -79,3 +79,23 @@ def test_verify_prepare_rejects_malformed_proofs():
     some[11 * 32 + 32] = 1                                                      # kzg10::Proof::random_v must be None
     with pytest.raises(z.ZktError):
         _prepare(cv, "merlin", vk, srs, pis, bytes(some))
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
+def test_multi_scalar_mul_on_arbitrary_points_matches_the_oracle(cv):
+    """HomomorphicCommitment::multi_scalar_mul (commitment.rs:32-45): 13 arbitrary points (one of them the identity),
+    Montgomery and canonical scalars, zero / one / r - 1 among them; and the empty sum."""
+    p = cv.fr.p
+    srs = K.srs_mont(cv, 0xABCD, 13)
+    pts = K.points_from_mont(cv, srs)
+    pts[4] = None
+    srs[4] = 0
+    sc = field_elems(p, 77, 13)
+    sc[0], sc[1], sc[2] = 0, 1, p - 1
+    want = C.msm_naive(cv, pts, sc)
+    got, inf = _lib.g1_msm_host(cv.name, srs, K.fr_to_mont(cv, sc))
+    assert (None if inf else K.points_from_mont(cv, got.reshape(1, -1))[0]) == want
+    got2, inf2 = _lib.g1_msm_host(cv.name, srs, K.ints_to_limbs(sc, 4), montgomery=False)
+    assert inf2 == inf and np.array_equal(got2, got)
+    L = cv.fq.limbs64
+    assert _lib.g1_msm_host(cv.name, np.zeros((0, 2 * L), np.uint64), np.zeros((0, 4), np.uint64))[1]

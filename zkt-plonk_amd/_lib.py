@@ -276,6 +276,26 @@ def g1_sum_host(curve, points) -> tuple:
     return out, bool(inf.value)
 
 
+def g1_msm_host(curve, points, scalars, montgomery: bool = True) -> tuple:
+    """HomomorphicCommitment::multi_scalar_mul (commitment.rs:32-45) on arbitrary points, on the host ->
+    (xy limbs, is_infinity)."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, words)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    assert pts.shape[0] == sc.shape[0]
+    out = np.zeros(words, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_g1_msm_host.argtypes = [ctypes.c_int, P64, P64, ctypes.c_size_t, ctypes.c_int, P64, ctypes.POINTER(ctypes.c_int)]
+    rc = L.zkt_g1_msm_host(cid, u64p(pts) if pts.size else None, u64p(sc) if sc.size else None, pts.shape[0], int(montgomery),
+                           u64p(out), ctypes.byref(inf))
+    if rc:
+        raise ZktError(rc, "zkt_g1_msm_host")
+    return out, bool(inf.value)
+
+
 class Transcript:
     """Built-in host transcript (T: TranscriptProtocol): kind 'merlin' (plonk-core/src/transcript.rs:46-109)
     or 'ethereum' (gadgets/src/transcript.rs:8-90).  Scalars / coordinates are canonical integers."""

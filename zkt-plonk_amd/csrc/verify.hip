@@ -304,6 +304,37 @@ struct Verifier {
 
 using namespace zkt;
 
+template <class C>
+static void g1_msm_host_t(const uint64_t* pts, const uint64_t* scalars, size_t n, int scalars_mont, uint64_t* out, int* out_inf) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    constexpr int L64 = Q::N / 2;
+    typename Verifier<C>::HX acc = hostec::hx_identity<Q>();
+    for (size_t i = 0; i < n; ++i) {
+        Affine<Q> a;
+        memcpy(a.x.v, pts + i * 2 * L64, Q::N * 4);
+        memcpy(a.y.v, pts + i * 2 * L64 + L64, Q::N * 4);
+        if (aff_is_inf<Q>(a)) continue;
+        Fe<R> s;
+        memcpy(s.v, scalars + 4 * i, 32);
+        if (!scalars_mont) s = fe_to_mont<R>(s);
+        acc = hostec::hx_add<Q>(acc, Verifier<C>::mul(Verifier<C>::to_hx(a), s));
+    }
+    const Affine<Q> r = xyzz_to_affine_host<Q>(hostec::hx_to<Q>(acc));
+    memcpy(out, r.x.v, Q::N * 4);
+    memcpy(out + L64, r.y.v, Q::N * 4);
+    if (out_inf) *out_inf = aff_is_inf<Q>(r) ? 1 : 0;
+}
+
+extern "C" int zkt_g1_msm_host(int curve_id, const uint64_t* points_xy_mont, const uint64_t* scalars, size_t n,
+                               int scalars_montgomery, uint64_t* out_xy_mont, int* out_is_infinity) {
+    if ((n && (!points_xy_mont || !scalars)) || !out_xy_mont) return ZKT_ERR_INVALID_ARGUMENT;
+    if (curve_id == ZKT_CURVE_BN254) g1_msm_host_t<Bn254Curve>(points_xy_mont, scalars, n, scalars_montgomery, out_xy_mont, out_is_infinity);
+    else if (curve_id == ZKT_CURVE_BLS12_381) g1_msm_host_t<Bls381Curve>(points_xy_mont, scalars, n, scalars_montgomery, out_xy_mont, out_is_infinity);
+    else return ZKT_ERR_INVALID_ARGUMENT;
+    return ZKT_OK;
+}
+
 extern "C" int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, uint64_t* out_pairs,
                                   int* out_is_infinity) {
     if (!in || !transcript || !out_pairs || !in->proof || !in->vk_commitments || !in->g || (in->n_pi && (!in->pi_roots || !in->pub_inputs)))
