@@ -41,3 +41,22 @@ def test_batched_poseidon_matches_the_native_spec(cv, width, half_full, partial)
                                 K.fr_to_mont(cv, field_elems(p, 2, 9)), K.fr_to_mont(cv, [tag])[0],
                                 np.zeros((4, 3, 4), np.uint64))          # arity 3 does not fit width 3
     ctx.close()
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
+def test_poseidon_committed_fixture(cv):
+    """tests/golden/vectors_r02.json: one width-5 permutation with splitmix64 constants."""
+    import json, os
+    import zkt_plonk_amd as z
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors_r02.json")) as f:
+        q = json.load(f)[cv.name]["poseidon"]
+    p = cv.fr.p
+    W = q["width"]
+    rc = field_elems(p, q["rc_seed"], (2 * q["half_full"] + q["partial"]) * W)
+    mds = [x for i in range(W) for x in field_elems(p, q["mds_seed"] + i, W)]
+    ins = K.fr_to_mont(cv, field_elems(p, q["input_seed"], 4)).reshape(1, 4, 4)
+    ctx = z.Context(cv.name, 0)
+    got = ctx.poseidon_hash_batch(W, q["half_full"], q["partial"], K.fr_to_mont(cv, rc), K.fr_to_mont(cv, mds),
+                                  K.fr_to_mont(cv, [q["domain_tag"]])[0], ins)
+    assert "%x" % K.fr_from_mont(cv, got)[0] == q["hash"]
+    ctx.close()

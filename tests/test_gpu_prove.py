@@ -220,6 +220,12 @@ def test_headline_configs_proof_bytes_equal_cpu_oracle(cvname, log_n, ctxs):
     want = FP.prove(cv, srs, keys, w["a"], w["b"], w["c"], w["table"], w["pi"], P.new_seeded_transcript(cv, vk), blinders)
     assert len(got) == (802 if cv.name == "bn254" else 1010)
     assert got == want
+    if cv.name == "bn254" and log_n == 14:     # the committed fixture of configs[0] (tests/golden/vectors_r02.json)
+        import hashlib, json, os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors_r02.json")) as f:
+            e = json.load(f)["config0_bn254_2_14"]
+        assert e["blinder_seed"] == 2020 + log_n and int(e["tau"], 16) == tau
+        assert hashlib.sha256(got).hexdigest() == e["proof_sha256"]
     pis = [w["pi"][k] for k in w["pi_pos"]]
     assert P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), pis)
 

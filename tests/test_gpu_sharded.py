@@ -38,6 +38,15 @@ def test_class_transform_is_the_decimated_coset_transform(cv):
                     assert np.array_equal(got, full[cls::G]), (log_big, in_len, G, cls)
     with pytest.raises(z.ZktError):
         ctx.ntt_class(5, 7, 4, rand_fr(rng, 8))        # class index outside the split
+    # the committed fixtures (tests/golden/vectors_r02.json)
+    import json
+    from helpers import digest
+    with open(os.path.join(ROOT, "tests", "golden", "vectors_r02.json")) as f:
+        fx = json.load(f)[cv.name]["ntt_class"]
+    for e in fx:
+        lg = e["G"].bit_length() - 1
+        x = K.fr_to_mont(cv, field_elems(cv.fr.p, e["seed"], e["in_len"]))
+        assert digest(K.fr_from_mont(cv, ctx.ntt_class(e["log_big"] - lg, e["log_big"], e["cls"], x))) == e["sha256"]
     ctx.close()
 
 
