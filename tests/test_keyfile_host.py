@@ -70,3 +70,64 @@ def test_malformed_key_files_are_rejected(tmp_path):
         _lib.keyfile_committer_key(str(f), cv.name)
     with pytest.raises(_lib.ZktError):
         _lib.keyfile_committer_key(str(tmp_path / "missing.bin"), cv.name)
+
+
+def test_readers_and_verifier_survive_mutated_inputs(tmp_path):
+    """Parsers of untrusted bytes (key files, proofs): a few hundred random truncations / byte flips / length-field
+    edits must end in a clean result or a ZktError, never in a crash or an out-of-bounds access (this test also runs
+    under AddressSanitizer + UBSan, tests/test_host_sanitize.py)."""
+    import random
+    import zkt_plonk_amd as z
+    cv = F.BN254
+    cs, n, srs, pk, vk = _setup(cv)
+    rnd = random.Random(1234)
+    blobs = {"pk": KF.prover_key_bytes(cv, pk), "vk": KF.verifier_key_bytes(cv, vk),
+             "ck": KF.committer_key_bytes(cv, K.points_from_mont(cv, srs[:40]))}
+    readers = {"pk": lambda p: _lib.keyfile_prover_key(p, cv.name), "vk": lambda p: _lib.keyfile_verifier_key(p, cv.name),
+               "ck": lambda p: _lib.keyfile_committer_key(p, cv.name, max_powers=rnd.choice([0, 1, 7, 40, 1000]))}
+
+    def mutate(b):
+        b = bytearray(b)
+        kind = rnd.randrange(4)
+        if kind == 0 and len(b) > 1:
+            del b[rnd.randrange(len(b)):]
+        elif kind == 1:
+            for _ in range(rnd.randrange(1, 6)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif kind == 2:                      # stomp on a plausible length field
+            at = rnd.choice([0, 8, 16, 24]) if len(b) > 32 else 0
+            b[at:at + 8] = rnd.choice([0, 1, 2 ** 32, 2 ** 63, 2 ** 64 - 1, len(b)]).to_bytes(8, "little")
+        else:
+            b += bytes(rnd.randrange(1, 40))
+        return bytes(b)
+
+    outcomes = {"ok": 0, "err": 0}
+    f = tmp_path / "m.bin"
+    for i in range(240):
+        name = ("pk", "vk", "ck")[i % 3]
+        f.write_bytes(mutate(blobs[name]))
+        try:
+            readers[name](str(f))
+            outcomes["ok"] += 1
+        except _lib.ZktError:
+            outcomes["err"] += 1
+    assert outcomes["err"] > 100 and outcomes["ok"] + outcomes["err"] == 240
+    # proofs through the verifier
+    from helpers import field_elems
+    be = K.CBackend(cv, K.srs_mont(cv, 0xF11E, n + 8))
+    pk2, epk2, vk2 = P.setup(be, [None] * (n + 8), cs, True)
+    proof = P.prove(be, [None] * (n + 8), pk2, epk2, vk2, cs, P.new_seeded_transcript(cv, vk2),
+                    field_elems(cv.fr.p, 3, P.NUM_BLINDERS)).serialize(cv)
+    commits = K.points_to_mont(cv, [vk2.commits[k] for k in z.PK_ORDER])
+    inf = [vk2.commits[k] is None for k in z.PK_ORDER]
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    seen_err = 0
+    for i in range(120):
+        tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=32)
+        z.seed_transcript(tr, vk2.n, vk2.commits)
+        try:
+            _lib.verify_prepare(cv.name, vk2.n, commits, inf, K.fr_to_mont(cv, vk2.pi_roots), K.fr_to_mont(cv, pis),
+                                mutate(proof), be.srs_arr[0], tr)
+        except _lib.ZktError:
+            seen_err += 1
+    assert seen_err > 30
