@@ -178,3 +178,40 @@ def test_torch_comm_device_path_on_one_rank():
            "--master-port", str(pnum), os.path.join(ROOT, "tests", "sharded_worker.py"), "devcomm"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DEVCOMM OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_sharded_mode_refuses_a_key_that_is_not_the_ranks_slice():
+    """With a communicator attached, the whole key (zkt_srs_load) or another rank's slice would turn every combined
+    commitment into a multiple of the right one: setup and prove refuse before any collective is entered."""
+    import zkt_plonk_amd as z
+    from zkt_plonk_amd import parallel as par
+    cv = F.BN254
+    cs = P.synthetic_circuit(cv, 100, 16, seed=2)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, 77, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    evals = {k: K.fr_to_mont(cv, v) for k, v in P.setup_evals(be, cs).items()}
+    ctx = z.Context(cv.name, 0)
+    comm = par.LocalGroup(2).comm(0)          # the partner never shows up: no collective may be reached
+    ctx.set_comm(comm)
+    ctx.srs_load(srs_arr)                                        # the whole key
+    with pytest.raises(z.ZktError) as e:
+        z.GpuProver.setup(ctx, n.bit_length() - 1, evals)
+    assert e.value.code == 1 and comm.calls == 0
+    lo, hi = par.shard_range(n + 8, 1, 2)
+    ctx.srs_load_slice(srs_arr[lo:hi], lo, n + 8)                # rank 1's slice on rank 0
+    with pytest.raises(z.ZktError) as e:
+        z.GpuProver.setup(ctx, n.bit_length() - 1, evals)
+    assert e.value.code == 1 and comm.calls == 0
+    ctx.set_comm(None)                                           # detached: an ordinary single-GPU context again
+    ctx.srs_load(srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    z.GpuProver.setup(ctx, n.bit_length() - 1, evals)
+    a, b, c = (K.fr_to_mont(cv, w) for w in cs.wire_evals(cs.n_gates))
+    pos = sorted(cs.pi)
+    blinders = field_elems(cv.fr.p, 1, P.NUM_BLINDERS)
+    tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)
+    got = ctx.prove(a, b, c, K.fr_to_mont(cv, cs.table), pos, K.fr_to_mont(cv, [cs.pi[i] for i in pos]),
+                    K.fr_to_mont(cv, blinders), tr)
+    assert got == P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    ctx.close()

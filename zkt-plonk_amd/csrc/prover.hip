@@ -1066,9 +1066,25 @@ int zkt_circuit_load(zkt_ctx* c, int log_n, const uint64_t* const* pk_polys, con
     return circuit_load_t<Bls381Curve>(c, log_n, pk_polys, pk_lens);
 }
 
+// With a communicator attached every rank must hold exactly its zkt_shard_range of the key: a rank that loaded the
+// whole key (or somebody else's slice) would make the combined commitments a multiple of the right ones.
+static int check_sharded_key(zkt_ctx* c) {
+    if (!c->sharded()) return ZKT_OK;
+    size_t off = 0, cnt = 0, total = 0, lo = 0, hi = 0;
+    zkt::msm_slice(c, &off, &cnt, &total);
+    (void)zkt_shard_range(total, c->comm.vt.rank, c->comm.vt.world, &lo, &hi);
+    if (off != lo || off + cnt != hi)
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT,
+                       "sharded proof: this rank must load powers zkt_shard_range(total, rank, world) with zkt_srs_load_slice");
+    if (c->circuit && c->circuit->G != c->comm.vt.world)
+        return set_err(c, ZKT_ERR_NOT_LOADED, "the circuit was loaded for another communicator");
+    return ZKT_OK;
+}
+
 static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr, uint8_t* out, size_t cap, size_t* len) {
     if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    if (int rc0 = check_sharded_key(c)) return rc0;
     (void)hipSetDevice(c->device);
     std::vector<uint8_t> proof;
     int rc;
@@ -1100,6 +1116,7 @@ int zkt_circuit_setup(zkt_ctx* c, int log_n, const uint64_t* const* evals, const
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
     (void)hipSetDevice(c->device);
     if (log_n < 3 || log_n > 26) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "circuit bound out of range");
+    if (int rc0 = check_sharded_key(c)) return rc0;
     if (c->curve == ZKT_CURVE_BN254)
         return circuit_setup_t<Bn254Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
     return circuit_setup_t<Bls381Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
