@@ -41,10 +41,31 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(zkt_[a-z0-9_]+)\s*\(", text)))
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's wheel carries its own libamdhip64.  Two HIP runtimes in one process do not share the device: whichever
+    initialises second finds no GPU.  When torch is installed, its copy is mapped first (by path, without importing
+    torch), so that this library and torch resolve to the same runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads the HIP library.  Raises loudly when it has not been built: there is no fallback."""
     global _lib
     if _lib is None:
+        if not os.environ.get("ZKT_LIB_PATH"):
+            _share_torch_hip_runtime()
         if not os.path.exists(_LIB):
             raise ImportError(
                 "libzkt_plonk_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
