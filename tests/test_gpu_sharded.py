@@ -220,16 +220,17 @@ def test_sharded_mode_refuses_a_key_that_is_not_the_ranks_slice():
 def test_library_and_torch_share_one_hip_runtime_in_either_import_order():
     """PyTorch ships its own libamdhip64; loaded second it used to find no device.  The binding maps torch's copy first,
     so a context created BEFORE torch touches the GPU leaves torch fully functional (fresh process)."""
-    code = ("import sys; sys.path.insert(0, %r)\\n"
-            "import numpy as np\\n"
-            "import zkt_plonk_amd as z\\n"
-            "ctx = z.Context('bn254', 0)\\n"
-            "x = ctx.ntt(4, np.ones((16, 4), dtype=np.uint64))\\n"
-            "import torch\\n"
-            "torch.cuda.set_device(0)\\n"
-            "t = torch.arange(8, device='cuda').sum().item()\\n"
-            "y = ctx.ntt(4, np.ones((16, 4), dtype=np.uint64))\\n"
-            "assert t == 28 and np.array_equal(x, y)\\n"
-            "print('SHARED OK')\\n") % ROOT
+    code = "\n".join([
+        "import sys; sys.path.insert(0, %r)" % ROOT,
+        "import numpy as np",
+        "import zkt_plonk_amd as z",
+        "ctx = z.Context('bn254', 0)",
+        "x = ctx.ntt(4, np.ones((16, 4), dtype=np.uint64))",
+        "import torch",
+        "torch.cuda.set_device(0)",
+        "t = torch.arange(8, device='cuda').sum().item()",
+        "y = ctx.ntt(4, np.ones((16, 4), dtype=np.uint64))",
+        "assert t == 28 and np.array_equal(x, y)",
+        "print('SHARED OK')"])
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARED OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
