@@ -116,3 +116,38 @@ def test_ntt_full_size_properties(cv, ctxs):
             assert K.fr_from_mont(cv, ys[k:k + 1])[0] == want
 
 
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_domain_and_commitment_mirrors_of_the_reference_seams(cv, ctxs):
+    """GpuDomain ~ D: EvaluationDomain + EvaluationDomainExt (util.rs:27-140) and GpuKZG10 ~ PC: HomomorphicCommitment
+    (commitment.rs:10-46), the two generic seams of ZKTPlonk (plonk.rs:39-52), against the oracle's Domain / commit."""
+    import zkt_plonk_amd as z
+    from oracle.ntt import Domain
+    from oracle import curve as C
+    ctx = ctxs[cv.name]
+    p = cv.fr.p
+    for num_coeffs in (1, 5, 8, 100, 1000):                      # D::new rounds up to a power of two
+        d, o = z.GpuDomain(ctx, num_coeffs), Domain(cv.fr, num_coeffs)
+        assert d.size() == o.size and d.log_size_of_group() == o.log_size
+        assert K.fr_from_mont(cv, d.group_gen().reshape(1, 4)) == [o.group_gen]
+        x = field_elems(p, 40 + num_coeffs, min(num_coeffs, o.size))
+        xm = K.fr_to_mont(cv, x)
+        assert K.fr_from_mont(cv, d.fft(xm)) == o.fft(x)
+        assert K.fr_from_mont(cv, d.ifft(xm)) == o.ifft(x)
+        assert K.fr_from_mont(cv, d.coset_fft(xm)) == o.coset_fft(x)
+        assert K.fr_from_mont(cv, d.coset_ifft(xm)) == o.coset_ifft(x)
+    with pytest.raises(z.ZktError) as e:
+        z.GpuDomain(ctx, (1 << cv.fr.two_adicity) + 1)           # Error::InvalidEvalDomainSize (prove.rs:77-81)
+    assert e.value.code == 2
+    srs = K.srs_mont(cv, 0xC0DE, 300)
+    pc = z.GpuKZG10(ctx, srs)
+    coeffs = field_elems(p, 9, 257)
+    xy, inf = pc.commit(K.fr_to_mont(cv, coeffs))
+    assert (None if inf else K.points_from_mont(cv, xy.reshape(1, -1))[0]) == C.msm_naive(cv, K.points_from_mont(cv, srs[:257]), coeffs)
+    with pytest.raises(z.ZktError) as e:
+        pc.commit(np.zeros((301, 4), dtype=np.uint64))
+    assert e.value.code == 5
+    sc = field_elems(p, 10, 13)
+    xy, inf = pc.multi_scalar_mul(srs[20:33], K.fr_to_mont(cv, sc))
+    assert (None if inf else K.points_from_mont(cv, xy.reshape(1, -1))[0]) == C.msm_naive(cv, K.points_from_mont(cv, srs[20:33]), sc)

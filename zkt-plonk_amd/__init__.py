@@ -3,7 +3,8 @@
 Host-side mirror of the reference's two generic seams:
 
 * ``GpuDomain``        ~ ``D: EvaluationDomain<F> + EvaluationDomainExt<F>``  (plonk-core/src/util.rs:27-140)
-* ``Context.msm``      ~ ``PC::commit`` = kzg10 commit = G1 MSM over the loaded powers (plonk-core/src/commitment.rs:24-46)
+* ``GpuKZG10``         ~ ``PC: HomomorphicCommitment<F>``: commit = G1 MSM over the loaded powers, multi_scalar_mul
+                         (plonk-core/src/commitment.rs:10-46)
 * ``GpuProver.prove``  ~ ``proof_system::prove``  (plonk-core/src/proof_system/prove.rs:59-470; the openings live inside it)
 * ``parallel``         ~ one proof or many across the GPUs of a node (communicators, SRS slices)
 
@@ -16,6 +17,6 @@ from ._lib import (  # noqa: F401
     Context, ZktError, Transcript, lib, lib_path, CURVE_BN254, CURVE_BLS12_381, curve_id, declared_symbols,
 )
 from .domain import GpuDomain  # noqa: F401
-from .prover import GpuProver, seed_transcript, PK_ORDER, NUM_BLINDERS  # noqa: F401
+from .prover import GpuProver, GpuKZG10, seed_transcript, PK_ORDER, NUM_BLINDERS  # noqa: F401
 
 __all__ = ["Context", "ZktError", "GpuDomain", "lib", "lib_path", "CURVE_BN254", "CURVE_BLS12_381"]

@@ -22,6 +22,25 @@ def seed_transcript(tr: Transcript, n: int, vk_commits: Dict[str, Optional[tuple
     return tr
 
 
+class GpuKZG10:
+    """Host-side mirror of the Commitment seam ``PC: HomomorphicCommitment<F>`` = KZG10 (plonk-core/src/commitment.rs:10-46):
+    ``commit`` = kzg10::commit = MSM over the loaded powers (device), ``multi_scalar_mul`` on arbitrary commitments
+    (host, commitment.rs:32-45).  Openings are produced inside ``GpuProver.prove``."""
+
+    def __init__(self, ctx: Context, powers_of_g: np.ndarray = None):
+        self.ctx = ctx
+        if powers_of_g is not None:
+            ctx.srs_load(powers_of_g)            # ck.powers_of_g, as PC::trim leaves them (plonk.rs:79-85)
+
+    def commit(self, coeffs: np.ndarray):
+        """-> (xy limbs, is_infinity); raises ZktError(5) = TooManyCoefficients beyond the loaded powers."""
+        return self.ctx.msm(coeffs, 0, True)
+
+    def multi_scalar_mul(self, commitments: np.ndarray, scalars: np.ndarray):
+        from ._lib import g1_msm_host
+        return g1_msm_host(self.ctx.curve, commitments, scalars, True)
+
+
 class GpuProver:
     """Device-resident circuit + SRS; one instance per (circuit, context)."""
 
