@@ -230,7 +230,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
         } else {
             x = (g < a.in_len) ? fx_unpack<P>(fe_load<P>(in + g)) : fx_zero<P>();
         }
-        if (in_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(in_row + r)));
+        // the prover's coset transforms are fed n + 8 coefficients on a domain of 4n: three rows in four are padding,
+        // and whole wavefronts see nothing but padding (a wave covers consecutive rows), so the branch is uniform
+        if (in_row && (a.in_raw || g < a.in_len)) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(in_row + r)));
         if (tw) {
             uint64_t ti = LAST ? (tw_base + ((uint64_t)c << LOG_R) + r) : (tw_base + r);
             x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(tw + ti)));
