@@ -683,3 +683,14 @@ def test_gpu_proof_through_the_product_verifier(cv, ctxs):
                                      K.fr_to_mont(cv, pis), proof, srs_arr[0], tr)
     pts = [None if inf[i] else K.points_from_mont(cv, pairs[i:i + 1])[0] for i in range(4)]
     assert pts[0] == C.scalar_mul(cv, tau, pts[1]) and pts[2] == C.scalar_mul(cv, tau, pts[3])
+
+
+def test_short_soak_of_chained_proofs():
+    """tools/soak.py in its short form: 400 chained proofs at n = 2^12 over three witnesses x two table orders in device
+    and host form, announcements honoured, dropped or withheld at random, an unrelated MSM now and then; every proof must
+    reproduce the bytes its inputs gave unchained."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "12", "400"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "SOAK OK: 400 proofs, 0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
