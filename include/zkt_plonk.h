@@ -280,7 +280,8 @@ typedef struct {
 int zkt_poseidon_hash_batch(zkt_ctx* ctx, const zkt_poseidon_params* params, const uint64_t* inputs, size_t batch, int arity,
                             uint64_t* out_hashes, uint64_t* out_states);
 
-/* ---- Verifier, everything but the pairings (proof_system/proof.rs:285-503) ------------------------
+/* ---- Verifier (proof_system/proof.rs:285-503): zkt_verify_prepare = everything but the pairings,
+ * ---- zkt_pairing_product_is_one = the pairings, zkt_verify = both ------------------------------------------------
  * Deserialises the proof (proof.rs:98-155; points are decompressed and checked to be on the curve), replays the
  * transcript, computes r0 (proof.rs:163-217) and the linearisation commitment (proof.rs:220-282, the 13-point
  * multi_scalar_mul of commitment.rs:32-45), and folds each of the two SonicKZG10::check calls (proof.rs:420-500) into
@@ -302,6 +303,17 @@ typedef struct {
 } zkt_verify_inputs;
 int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, uint64_t* out_pairs,
                        int* out_is_infinity);
+
+/* The pairing check itself, on the host: prod_i e(P_i, Q_i) == 1 for P_i in G1 ((x, y) Montgomery limbs) and Q_i in G2
+ * (arkworks' Fp2 layout: x.c0, x.c1, y.c0, y.c1; all-zero = infinity).  The reduced Tate pairing is computed, not
+ * arkworks' optimal ate: the two are powers of one another with an exponent prime to r, so "is the product one" has the
+ * same answer (csrc/pairing.hpp).  ~5 ms per pairing.  Points off the curve / twist -> ZKT_ERR_INVALID_ARGUMENT; G2
+ * subgroup membership is the caller's business (h and beta h come from the trusted VerifierKey). */
+int zkt_pairing_product_is_one(int curve_id, const uint64_t* g1_xy_mont, const uint64_t* g2_xy_mont, size_t n, int* is_one);
+/* The whole of Proof::verify (proof_system/proof.rs:285-503): zkt_verify_prepare, then e(L, h) e(-W, beta h) == 1 for both
+ * openings.  h, beta_h: SonicKZG10 VerifierKey::h and ::beta_h (G2).  *accepted = 1 / 0 (Error::ProofVerificationError). */
+int zkt_verify(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, const uint64_t* h_g2_mont,
+               const uint64_t* beta_h_g2_mont, int* accepted);
 
 /* HomomorphicCommitment::multi_scalar_mul (commitment.rs:32-45) for ARBITRARY points: the verifier's 13-point
  * linearisation commitment and similar short combinations.  Host arithmetic (double-and-add on 64-bit limbs): at this

@@ -233,6 +233,49 @@ def verify_prepare(curve, n: int, vk_commits: np.ndarray, vk_inf, pi_roots: np.n
     return out, np.array([bool(x) for x in oinf])
 
 
+def pairing_product_is_one(curve, g1_points: np.ndarray, g2_points: np.ndarray) -> bool:
+    """prod_i e(P_i, Q_i) == 1 on the host (zkt_pairing_product_is_one).  g1: (n, 2*fq_limbs); g2: (n, 4*fq_limbs) =
+    x.c0, x.c1, y.c0, y.c1; Montgomery limbs."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 4 if cid == CURVE_BN254 else 6
+    g1 = np.ascontiguousarray(g1_points, dtype=np.uint64).reshape(-1, 2 * words)
+    g2 = np.ascontiguousarray(g2_points, dtype=np.uint64).reshape(-1, 4 * words)
+    assert g1.shape[0] == g2.shape[0]
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_pairing_product_is_one.argtypes = [ctypes.c_int, P64, P64, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+    one = ctypes.c_int(0)
+    rc = L.zkt_pairing_product_is_one(cid, u64p(g1) if g1.size else None, u64p(g2) if g2.size else None, g1.shape[0],
+                                      ctypes.byref(one))
+    if rc:
+        raise ZktError(rc, "zkt_pairing_product_is_one")
+    return bool(one.value)
+
+
+def verify(curve, n: int, vk_commits, vk_inf, pi_roots, pub_inputs, proof: bytes, g_xy, h_g2, beta_h_g2, transcript) -> bool:
+    """Proof::verify (proof_system/proof.rs:285-503) on the host, pairings included (zkt_verify)."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    vk_commits = np.ascontiguousarray(vk_commits, dtype=np.uint64).reshape(10, words)
+    pi_roots = np.ascontiguousarray(pi_roots, dtype=np.uint64).reshape(-1, 4)
+    pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1, 4)
+    g_xy = np.ascontiguousarray(g_xy, dtype=np.uint64).reshape(words)
+    h = np.ascontiguousarray(h_g2, dtype=np.uint64).reshape(2 * words)
+    bh = np.ascontiguousarray(beta_h_g2, dtype=np.uint64).reshape(2 * words)
+    inf = (ctypes.c_int * 10)(*[int(bool(x)) for x in vk_inf])
+    null = ctypes.POINTER(ctypes.c_uint64)()
+    inp = VerifyInputs(n, u64p(vk_commits), inf, u64p(pi_roots) if pi_roots.size else null,
+                       u64p(pub_inputs) if pub_inputs.size else null, pi_roots.shape[0], proof, len(proof), u64p(g_xy))
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_verify.argtypes = [ctypes.c_int, ctypes.POINTER(VerifyInputs), ctypes.c_void_p, P64, P64, ctypes.POINTER(ctypes.c_int)]
+    ok = ctypes.c_int(0)
+    rc = L.zkt_verify(cid, ctypes.byref(inp), transcript.handle, u64p(h), u64p(bh), ctypes.byref(ok))
+    if rc:
+        raise ZktError(rc, "zkt_verify")
+    return bool(ok.value)
+
+
 class ProveInputs(ctypes.Structure):
     _fields_ = [("a_evals", ctypes.POINTER(ctypes.c_uint64)), ("b_evals", ctypes.POINTER(ctypes.c_uint64)),
                 ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),

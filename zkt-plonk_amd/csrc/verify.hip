@@ -9,6 +9,7 @@
 #include "ec.hpp"
 #include "hostec.hpp"
 #include "hostinv.hpp"
+#include "pairing.hpp"
 #include "transcript.hpp"
 
 #include <cstring>
@@ -333,6 +334,87 @@ extern "C" int zkt_g1_msm_host(int curve_id, const uint64_t* points_xy_mont, con
     else if (curve_id == ZKT_CURVE_BLS12_381) g1_msm_host_t<Bls381Curve>(points_xy_mont, scalars, n, scalars_montgomery, out_xy_mont, out_is_infinity);
     else return ZKT_ERR_INVALID_ARGUMENT;
     return ZKT_OK;
+}
+
+template <class C>
+static int pairing_inputs(const uint64_t* g1, const uint64_t* g2, size_t n, std::vector<typename pairing::Tower<C>::G1>& ps,
+                          std::vector<typename pairing::Tower<C>::G2>& qs) {
+    using Q = typename C::Fq;
+    using T = pairing::Tower<C>;
+    constexpr int L64 = Q::N / 2;
+    ps.resize(n);
+    qs.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        Fe<Q> c[6];
+        memcpy(c[0].v, g1 + i * 2 * L64, Q::N * 4);
+        memcpy(c[1].v, g1 + i * 2 * L64 + L64, Q::N * 4);
+        for (int k = 0; k < 4; ++k) memcpy(c[2 + k].v, g2 + i * 4 * L64 + (size_t)k * L64, Q::N * 4);
+        ps[i].inf = fe_is_zero<Q>(c[0]) && fe_is_zero<Q>(c[1]);
+        ps[i].x = hostec::hf_from<Q>(c[0]);
+        ps[i].y = hostec::hf_from<Q>(c[1]);
+        qs[i].inf = fe_is_zero<Q>(c[2]) && fe_is_zero<Q>(c[3]) && fe_is_zero<Q>(c[4]) && fe_is_zero<Q>(c[5]);
+        qs[i].x = typename T::E2{hostec::hf_from<Q>(c[2]), hostec::hf_from<Q>(c[3])};
+        qs[i].y = typename T::E2{hostec::hf_from<Q>(c[4]), hostec::hf_from<Q>(c[5])};
+        if (!T::g1_on_curve(ps[i]) || !T::g2_on_twist(qs[i])) return ZKT_ERR_INVALID_ARGUMENT;
+    }
+    return ZKT_OK;
+}
+
+template <class C>
+static int pairing_check_t(const uint64_t* g1, const uint64_t* g2, size_t n, int* is_one) {
+    std::vector<typename pairing::Tower<C>::G1> ps;
+    std::vector<typename pairing::Tower<C>::G2> qs;
+    int rc = pairing_inputs<C>(g1, g2, n, ps, qs);
+    if (rc) return rc;
+    *is_one = pairing::Tower<C>::product_is_one(ps.data(), qs.data(), n) ? 1 : 0;
+    return ZKT_OK;
+}
+
+extern "C" int zkt_pairing_product_is_one(int curve_id, const uint64_t* g1_xy_mont, const uint64_t* g2_xy_mont, size_t n,
+                                          int* is_one) {
+    if (!is_one || (n && (!g1_xy_mont || !g2_xy_mont))) return ZKT_ERR_INVALID_ARGUMENT;
+    if (curve_id == ZKT_CURVE_BN254) return pairing_check_t<Bn254Curve>(g1_xy_mont, g2_xy_mont, n, is_one);
+    if (curve_id == ZKT_CURVE_BLS12_381) return pairing_check_t<Bls381Curve>(g1_xy_mont, g2_xy_mont, n, is_one);
+    return ZKT_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, uint64_t* out_pairs,
+                                  int* out_is_infinity);
+
+// The whole of Proof::verify (proof.rs:285-503): zkt_verify_prepare, then for each opening e(L, h) * e(-W, beta h) == 1
+template <class C>
+static int verify_t(int curve_id, const zkt_verify_inputs* in, zkt_transcript* tr, const uint64_t* h, const uint64_t* beta_h,
+                    int* accepted) {
+    using Q = typename C::Fq;
+    constexpr int L64 = Q::N / 2;
+    uint64_t pairs[4 * 12];
+    int inf[4];
+    int rc = zkt_verify_prepare(curve_id, in, tr, pairs, inf);
+    if (rc) return rc;
+    *accepted = 1;
+    for (int k = 0; k < 2 && *accepted; ++k) {
+        uint64_t g1[2 * 12], g2[2 * 4 * 6];
+        memcpy(g1, pairs + (size_t)(2 * k) * 2 * L64, 2 * L64 * 8);            // L
+        Fe<Q> wy;                                                               // -W
+        memcpy(g1 + 2 * L64, pairs + (size_t)(2 * k + 1) * 2 * L64, L64 * 8);
+        memcpy(wy.v, pairs + (size_t)(2 * k + 1) * 2 * L64 + L64, L64 * 8);
+        if (!inf[2 * k + 1]) wy = fe_neg<Q>(wy);
+        memcpy(g1 + 3 * L64, wy.v, L64 * 8);
+        memcpy(g2, h, 4 * L64 * 8);
+        memcpy(g2 + 4 * L64, beta_h, 4 * L64 * 8);
+        int one = 0;
+        if ((rc = pairing_check_t<C>(g1, g2, 2, &one))) return rc;
+        if (!one) *accepted = 0;    // Error::ProofVerificationError { step: k + 1 }
+    }
+    return ZKT_OK;
+}
+
+extern "C" int zkt_verify(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, const uint64_t* h_g2_mont,
+                          const uint64_t* beta_h_g2_mont, int* accepted) {
+    if (!in || !transcript || !h_g2_mont || !beta_h_g2_mont || !accepted) return ZKT_ERR_INVALID_ARGUMENT;
+    if (curve_id == ZKT_CURVE_BN254) return verify_t<Bn254Curve>(curve_id, in, transcript, h_g2_mont, beta_h_g2_mont, accepted);
+    if (curve_id == ZKT_CURVE_BLS12_381) return verify_t<Bls381Curve>(curve_id, in, transcript, h_g2_mont, beta_h_g2_mont, accepted);
+    return ZKT_ERR_INVALID_ARGUMENT;
 }
 
 extern "C" int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, uint64_t* out_pairs,
