@@ -683,6 +683,25 @@ def test_gpu_proof_through_the_product_verifier(cv, ctxs):
                                      K.fr_to_mont(cv, pis), proof, srs_arr[0], tr)
     pts = [None if inf[i] else K.points_from_mont(cv, pairs[i:i + 1])[0] for i in range(4)]
     assert pts[0] == C.scalar_mul(cv, tau, pts[1]) and pts[2] == C.scalar_mul(cv, tau, pts[3])
+    # ... and through the complete verifier, pairings included (zkt_verify), with SonicKZG10's h and beta h = tau h
+    from oracle import pairing as PR
+    from test_pairing_host import g2_mont
+    T = PR.Tower(cv)
+    H = PR.G2_GENERATORS[cv.name]
+    commits = K.points_to_mont(cv, [vk.commits[k] for k in z.PK_ORDER])
+    vinf = [vk.commits[k] is None for k in z.PK_ORDER]
+
+    def full(raw, bh):
+        t2 = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+        z.seed_transcript(t2, vk.n, vk.commits)
+        return _lib.verify(cv.name, vk.n, commits, vinf, K.fr_to_mont(cv, vk.pi_roots), K.fr_to_mont(cv, pis), raw, srs_arr[0],
+                           g2_mont(cv, [H])[0], bh, t2)
+
+    assert full(proof, g2_mont(cv, [T.g2_mul(tau, H)])[0])
+    assert not full(proof, g2_mont(cv, [T.g2_mul(tau + 1, H)])[0])
+    flipped = bytearray(proof)
+    flipped[-5] ^= 2
+    assert not full(bytes(flipped), g2_mont(cv, [T.g2_mul(tau, H)])[0])
 
 
 def test_short_soak_of_chained_proofs():
