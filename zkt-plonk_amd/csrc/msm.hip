@@ -21,6 +21,7 @@
 #include "ecx.hpp"
 #include "hostec.hpp"
 
+#include <algorithm>
 #include <cstring>
 
 namespace zkt {
@@ -717,11 +718,6 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if ((rc = dev_alloc(c, (void**)&st->offsets[i], ((size_t)st->nb1 * 256 + 2) * 4))) return rc;
         if ((rc = dev_alloc(c, (void**)&st->heavy[i], ((size_t)st->B + 2) * 4))) return rc;
     }
-    size_t max_chunks = (m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN;
-    for (int i = 0; i < MsmState::SLOTS; ++i)
-        if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
-    size_t nseg = st->B / MSM_SEG;
     {
         int blocks_per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
@@ -730,6 +726,13 @@ static int msm_setup(zkt_ctx* c, size_t count) {
             blocks_per_cu > 0 && cus > 0)
             st->acc_threads = (size_t)blocks_per_cu * cus * 256;
     }
+    // chunk = max(ceil(pairs / acc_threads), MSM_CHUNK_MIN) pairs per thread, so an MSM never cuts its pairs into more
+    // than acc_threads chunks (nor more than pairs / MSM_CHUNK_MIN): that bounds the piece array of every slot
+    size_t max_chunks = std::min((m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN, st->acc_threads + 1);
+    for (int i = 0; i < MsmState::SLOTS; ++i)
+        if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
+    size_t nseg = st->B / MSM_SEG;
     ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
