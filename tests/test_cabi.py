@@ -34,3 +34,15 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
+
+
+def test_public_header_is_plain_c():
+    """The drop-in boundary is a C ABI: include/zkt_plonk.h must compile as C99 on its own (no C++, no torch types)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "zkt_plonk.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(hdr).read()
+    assert "torch" not in text and "std::" not in text
