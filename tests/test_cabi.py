@@ -44,5 +44,6 @@ def test_public_header_is_plain_c():
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    text = open(hdr).read()
-    assert "torch" not in text and "std::" not in text
+    import re
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)      # comments may mention torch.distributed
+    assert "torch" not in code and "std::" not in code and "class " not in code
