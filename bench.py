@@ -397,10 +397,12 @@ def main():
     # ---- ONE proof across all the GPUs (SURVEY.md 8e / BASELINE.json configs[4]) -------------------------------------
     if world > 1 and args.shard != "proofs":
         refs = [ctx.prove_prepared(preps[k], transcript()) for k in range(2)]        # this GPU alone, for the bytes
+        guard = leg_watchdog(rank, out, float(os.environ.get("ZKT_SHARD_LEG_TIMEOUT", "300")))
         try:
             sh = sharded_leg(z, par, dist, dev, args, fld, tau, evals_keep, vk, host_w, table, pis, gates, refs, barrier)
         except Exception as e:      # reported, never fatal for the headline
             sh = {"error": "%s: %s" % (type(e).__name__, e)}
+        guard.cancel()
         out["single_proof_sharded"] = sh
         if args.shard == "proof" and "ms_per_proof" in sh:
             out.update(value=round(1e3 / sh["ms_per_proof"], 4), ms_per_step=sh["ms_per_proof"], scaling="strong")
@@ -415,6 +417,26 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def leg_watchdog(rank, out, seconds):
+    """The single-proof leg is an extra: if a rank is still inside it after `seconds` (a collective waiting for a peer that
+    failed), every rank's own timer ends its process, and rank 0 first prints the headline line measured before the leg."""
+    import threading
+
+    def give_up():
+        if rank == 0:
+            o = dict(out)
+            o["single_proof_sharded"] = {"error": "no result within %.0f s; leg abandoned, the headline is unaffected" % seconds}
+            print(json.dumps(o), flush=True)
+        sys.stderr.write("bench.py rank %d: single-proof leg abandoned after %.0f s\n" % (rank, seconds))
+        sys.stderr.flush()
+        os._exit(0)
+
+    t = threading.Timer(seconds, give_up)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis, gates, refs, barrier):
