@@ -358,6 +358,14 @@ int zkt_g1_sum_host(int curve_id, const uint64_t* points_xy_mont, size_t count, 
 /* Elementwise Fr product on the device (out[i] = a[i]*b[i], Montgomery); test hook for the field
  * kernels. Host pointers. */
 int zkt_debug_fr_mul(zkt_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* The fused quotient pass alone (quotient_poly.rs:98-224), for per-kernel tests: t(x) on the 4n coset from the loaded
+ * circuit's ExtendedProverKey and caller-supplied witness cosets.  challenges: alpha beta gamma delta epsilon (5 x 4
+ * words); wit: nine HOST vectors of 4n elements in the order a b c pi z1 z2 t h1 h2 (quotient_poly.rs:52-96).  With
+ * n_pi > 0 (at most 16) wit[3] is ignored and PI is evaluated the way the prover does for few public inputs, from
+ * rotations of the l1 coset (pi_pos: gate indices, pi_vals: 4 words each).  out: 4n elements.  Everything in arkworks
+ * Montgomery words.  Whole-coset (single-GPU) circuits only. */
+int zkt_debug_quotient(zkt_ctx* ctx, const uint64_t* challenges, const uint64_t* const* wit, const uint64_t* pi_pos,
+                       const uint64_t* pi_vals, size_t n_pi, uint64_t* out);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,7 @@ def lib():
         L.zkt_domain_group_gen.argtypes = [vp, ctypes.c_int, u64p]
         L.zkt_debug_params.argtypes = [vp, ctypes.c_int, u32p, ctypes.c_size_t]
         L.zkt_debug_fr_mul.argtypes = [vp, u64p, u64p, ctypes.c_size_t, u64p]
+        L.zkt_debug_quotient.argtypes = [vp, u64p, ctypes.POINTER(ctypes.c_void_p), u64p, u64p, ctypes.c_size_t, u64p]
         _bind_optional(L)
         _bind_prover(L)
         _lib = L
@@ -718,4 +719,19 @@ class Context:
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
         out = np.empty_like(a)
         self.check(self._L.zkt_debug_fr_mul(self._h, u64p(a), u64p(b), a.shape[0], u64p(out)))
+        return out
+
+    def debug_quotient(self, n: int, challenges, wit, pi_pos=(), pi_vals=None) -> np.ndarray:
+        """The quotient kernel alone over the loaded circuit (zkt_debug_quotient): challenges (5, 4) alpha beta gamma
+        delta epsilon; wit: nine (4n, 4) host arrays a b c pi z1 z2 t h1 h2 (wit[3] may be None with public inputs
+        given as positions + values).  Montgomery words throughout."""
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(5, 4)
+        keep = [None if w is None else np.ascontiguousarray(w, dtype=np.uint64).reshape(4 * n, 4) for w in wit]
+        assert len(keep) == 9
+        ptrs = (ctypes.c_void_p * 9)(*[None if w is None else w.ctypes.data for w in keep])
+        pos = np.ascontiguousarray(list(pi_pos), dtype=np.uint64)
+        vals = np.ascontiguousarray(pi_vals if len(pos) else np.zeros((0, 4)), dtype=np.uint64).reshape(-1, 4)
+        out = np.empty((4 * n, 4), dtype=np.uint64)
+        self.check(self._L.zkt_debug_quotient(self._h, u64p(ch), ptrs, u64p(pos) if len(pos) else None,
+                                              u64p(vals) if len(pos) else None, len(pos), u64p(out)))
         return out

@@ -1122,6 +1122,74 @@ int zkt_circuit_setup(zkt_ctx* c, int log_n, const uint64_t* const* evals, const
     return circuit_setup_t<Bls381Curve>(c, log_n, evals, eval_lens, evals_on_device, out_commitments, out_is_infinity);
 }
 
+// Test hook: the fused quotient pass on its own (quotient_poly.rs:98-224) over the loaded circuit's key cosets and
+// caller-supplied witness cosets, so that the kernel is compared point by point on inputs that satisfy nothing.
+extern "C++" template <class C>
+static void debug_pi_rows(const uint64_t* pi_pos, const uint64_t* pi_vals, size_t n_pi, uint32_t* tab) {
+    using R = typename C::Fr;
+    for (size_t i = 0; i < n_pi; ++i) {
+        tab[10 * i] = (uint32_t)(4 * pi_pos[i]);
+        const Fx<R> v = fx_unpack<R>(HostF<R>::from_words(pi_vals + 4 * i));
+        for (int w = 0; w < 9; ++w) tab[10 * i + 1 + w] = v.l[w];
+    }
+}
+
+int zkt_debug_quotient(zkt_ctx* c, const uint64_t* challenges, const uint64_t* const* wit, const uint64_t* pi_pos,
+                       const uint64_t* pi_vals, size_t n_pi, uint64_t* out) {
+    if (!c || !challenges || !wit || !out || (n_pi && (!pi_pos || !pi_vals)))
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    CircuitState& S = *c->circuit;
+    if (S.G != 1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "zkt_debug_quotient: whole-coset circuits only");
+    if (n_pi > (size_t)QUOTIENT_PI_DIRECT_MAX) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "too many direct public inputs");
+    for (size_t i = 0; i < n_pi; ++i)
+        if (pi_pos[i] >= S.n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "public input position out of range");
+    (void)hipSetDevice(c->device);
+    const size_t bytes = 4 * S.n * 32;
+    void* d[W_COUNT] = {};
+    void* d_out = nullptr;
+    uint32_t* d_tab = nullptr;
+    int rc = ZKT_OK;
+    for (int k = 0; k < W_COUNT && !rc; ++k) {
+        if (k == W_PI && n_pi) continue;
+        if (!wit[k]) rc = set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null witness coset");
+        else if (!(rc = dev_alloc(c, &d[k], bytes)) && hipMemcpy(d[k], wit[k], bytes, hipMemcpyHostToDevice) != hipSuccess)
+            rc = set_err(c, ZKT_ERR_HIP, "copy of a witness coset failed");
+    }
+    if (!rc) rc = dev_alloc(c, &d_out, bytes);
+    if (!rc && n_pi) {
+        std::vector<uint32_t> tab(10 * n_pi);
+        if (c->curve == ZKT_CURVE_BN254) debug_pi_rows<Bn254Curve>(pi_pos, pi_vals, n_pi, tab.data());
+        else debug_pi_rows<Bls381Curve>(pi_pos, pi_vals, n_pi, tab.data());
+        if (!(rc = dev_alloc(c, (void**)&d_tab, tab.size() * 4)) &&
+            hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = set_err(c, ZKT_ERR_HIP, "copy of the public-input rows failed");
+    }
+    if (!rc) {
+        QuotientArgs q{};
+        q.a = d[W_A]; q.b = d[W_B]; q.c = d[W_C]; q.pi = d[W_PI];
+        q.z1 = d[W_Z1]; q.z2 = d[W_Z2]; q.t = d[W_T]; q.h1 = d[W_H1]; q.h2 = d[W_H2];
+        q.q_m = S.coset[CS_QM]; q.q_l = S.coset[CS_QL]; q.q_r = S.coset[CS_QR]; q.q_o = S.coset[CS_QO];
+        q.q_c = S.coset[CS_QC]; q.q_lookup = S.coset[CS_QLOOKUP]; q.q_table = S.coset[CS_QTABLE];
+        q.sigma1 = S.coset[CS_S1]; q.sigma2 = S.coset[CS_S2]; q.sigma3 = S.coset[CS_S3];
+        q.x = S.coset[CS_X]; q.l1 = S.coset[CS_L1];
+        q.out = d_out;
+        memcpy(q.alpha, challenges, 32); memcpy(q.beta, challenges + 4, 32); memcpy(q.gamma, challenges + 8, 32);
+        memcpy(q.delta, challenges + 12, 32); memcpy(q.epsilon, challenges + 16, 32);
+        memcpy(q.zh_inv, S.zh_inv, sizeof(q.zh_inv));
+        q.n4 = 4 * S.n;
+        q.pi_tab = n_pi ? d_tab : nullptr;
+        q.n_pi_direct = (uint32_t)n_pi;
+        rc = quotient_pointwise(c, q);
+        if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(c, ZKT_ERR_HIP, "quotient kernel failed");
+        if (!rc && hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = set_err(c, ZKT_ERR_HIP, "copy back failed");
+    }
+    for (int k = 0; k < W_COUNT; ++k) dev_free(c, d[k]);
+    dev_free(c, d_out);
+    dev_free(c, d_tab);
+    return rc;
+}
+
 int zkt_prove_set_next(zkt_ctx* c, const zkt_prove_inputs* next) {
     if (!c) return ZKT_ERR_INVALID_ARGUMENT;
     if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
