@@ -263,16 +263,28 @@ def main():
     for _ in range(args.warmup):
         proof = one_proof()
     barrier()
-    ctx.profile_enable(os.environ.get("ZKT_BENCH_NO_EVENTS") is None)
+    # The dominant kernel is timed live over the timed region with HIP events on the stream it runs on (profile level 2:
+    # one event pair per MSM).  Every other scope (~80 more event records per proof, each a few microseconds of stream
+    # time) is measured in a separate, untimed pass of the same chained workload right after.
+    ctx.profile_enable(2 if os.environ.get("ZKT_BENCH_NO_EVENTS") is None else 0)
     t_start = time.perf_counter()
     for _ in range(args.steps):
         proof = one_proof()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t_start
     barrier()
-    prof = {k: ctx.profile_get(k) for k in ("msm_accumulate", "msm_main", "msm_fold", "msm_tail", "ntt_%d" % log_n,
-                                            "ntt_%d" % (log_n + 2), "quotient")}
-    ctx.profile_enable(False)
+    prof_acc = ctx.profile_get("msm_accumulate")
+    scope_names = ("msm_accumulate", "msm_main", "msm_fold", "msm_tail", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2), "quotient",
+                   "round1", "round2", "round3", "round4", "round5")
+    prof_steps = max(2, min(args.steps, 6))
+    ctx.profile_enable(1)
+    for _ in range(prof_steps):
+        one_proof()
+    torch.cuda.synchronize(dev)
+    prof = {k: ctx.profile_get(k) for k in scope_names}
+    ctx.profile_enable(0)
+    if prof_acc[0]:
+        prof["msm_accumulate"] = prof_acc          # the roofline's kernel time is the timed region's own
     red_dev = dev if (dist is None or dist.get_backend() == "nccl") else None
     elapsed = par.max_over_ranks(dist, elapsed, red_dev)   # whole-job time = slowest rank
     assert proof is not None and len(proof) == (802 if args.curve == "bn254" else 1010)
@@ -339,11 +351,13 @@ def main():
     mads_per_add = 6 * 2 * Lq * Lq + 2 * (Lq * (Lq + 1) // 2 + Lq * Lq) + 3 * Lq * Lq
     mad_ceiling = N_SIMD * 64 * CLOCK_HZ / MAD_CYCLES               # v_mad_u64_u32 issue ceiling, lanes/s
     traffic, traffic_src = pmc_traffic("k_msm_accumulate", args.curve, log_n)
+    valu_busy, valu_src = pmc_valu_busy("k_msm_accumulate", args.curve, log_n)
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_acc_s * 1e3, 4), "launches": acc_calls,
         "frac_of_mad_issue_ceiling": round(mads_per_add * mixed_adds / avg_acc_s / mad_ceiling, 4) if avg_acc_s > 0 else None,
+        "valu_busy": valu_busy, "valu_busy_source": valu_src,
         "note": "integer-ALU bound (v_mad_u64_u32 issue), not HBM bound: the contract's HBM fraction is reported, the "
                 "binding ceiling is frac_of_mad_issue_ceiling (see int_alu); traffic = measured gather traffic of W*n "
                 "random table points, not re-reads",
@@ -390,6 +404,10 @@ def main():
                    "chained": bool(chain), "distinct_witnesses": 2, "witness_on_device": True, "table_cached": True,
                    "proof_bytes": len(proof), "setup_s": round(setup_s, 1)},
         "roofline": roofline, "int_alu": int_alu, "kernels": ntt,
+        "rounds_ms": {k: round(prof[k][1] / prof[k][0], 3) for k in ("round1", "round2", "round3", "round4", "round5") if prof[k][0]},
+        "kernels_measured": "msm_accumulate: HIP events inside the timed region; the other scopes and rounds_ms: %d further "
+                            "chained proofs with every scope on, outside the timed region (stream time, first to last "
+                            "launch of the scope; round4 / round5 contain the early round1 / round2 of the next proof)" % prof_steps,
     }
     if latency is not None:
         out["latency"] = latency
@@ -397,9 +415,11 @@ def main():
     # ---- ONE proof across all the GPUs (SURVEY.md 8e / BASELINE.json configs[4]) -------------------------------------
     if world > 1 and args.shard != "proofs":
         refs = [ctx.prove_prepared(preps[k], transcript()) for k in range(2)]        # this GPU alone, for the bytes
-        guard = leg_watchdog(rank, out, float(os.environ.get("ZKT_SHARD_LEG_TIMEOUT", "300")))
+        progress = {"phase": "start"}
+        guard = leg_watchdog(rank, out, float(os.environ.get("ZKT_SHARD_LEG_TIMEOUT", "300")), progress)
         try:
-            sh = sharded_leg(z, par, dist, dev, args, fld, tau, evals_keep, vk, host_w, table, pis, gates, refs, barrier)
+            sh = sharded_leg(z, par, dist, dev, args, fld, tau, evals_keep, vk, host_w, table, pis, gates, refs, barrier,
+                             progress)
         except Exception as e:      # reported, never fatal for the headline
             sh = {"error": "%s: %s" % (type(e).__name__, e)}
         guard.cancel()
@@ -417,21 +437,33 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    # a sharded proof whose bytes differ from the single-GPU proof's is a correctness failure of the multi-GPU transport
+    # (the RCCL device path cannot be rehearsed on one-GPU boxes): the line above is printed, the run fails
+    sh = out.get("single_proof_sharded")
+    if isinstance(sh, dict) and sh.get("proof_bytes_equal_single_gpu") is False:
+        sys.stderr.write("bench.py rank %d: sharded proof bytes differ from the single-GPU proof\n" % rank)
+        sys.exit(4)
 
 
-def leg_watchdog(rank, out, seconds):
+def leg_watchdog(rank, out, seconds, progress):
     """The single-proof leg is an extra: if a rank is still inside it after `seconds` (a collective waiting for a peer that
-    failed), every rank's own timer ends its process, and rank 0 first prints the headline line measured before the leg."""
+    failed, a hung GPU), every rank's own timer ends its process.  Rank 0 first prints the headline line measured before the
+    leg, with the leg's last completed phase and collective count in its error record, and exits 0 (the headline is valid);
+    every other rank waits a few seconds for that line to get out and exits 3, so the launcher reports the stall."""
     import threading
 
     def give_up():
+        where = "last phase '%s', %d collective calls entered" % (progress.get("phase", "?"), progress.get("calls", lambda: -1)())
         if rank == 0:
             o = dict(out)
-            o["single_proof_sharded"] = {"error": "no result within %.0f s; leg abandoned, the headline is unaffected" % seconds}
+            o["single_proof_sharded"] = {"error": "no result within %.0f s (%s); leg abandoned, the headline is unaffected"
+                                                  % (seconds, where)}
             print(json.dumps(o), flush=True)
-        sys.stderr.write("bench.py rank %d: single-proof leg abandoned after %.0f s\n" % (rank, seconds))
+        else:
+            time.sleep(5.0)
+        sys.stderr.write("bench.py rank %d: single-proof leg abandoned after %.0f s (%s)\n" % (rank, seconds, where))
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(0 if rank == 0 else 3)
 
     t = threading.Timer(seconds, give_up)
     t.daemon = True
@@ -439,7 +471,7 @@ def leg_watchdog(rank, out, seconds):
     return t
 
 
-def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis, gates, refs, barrier):
+def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis, gates, refs, barrier, progress=None):
     """ONE proof on all the GPUs of the job: every commitment is an index-range-sharded MSM (each rank keeps 1 / N of
     the SRS, one all-gather of partial sums per prover round), the nine 4n-coset transforms and the quotient pass run on
     the rank's class of the coset with no exchange, one all-gather (4n x 32 B in total) precedes the inverse transform;
@@ -452,9 +484,14 @@ def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     comm = par.TorchComm(dist, dev)
     ctx.set_comm(comm)
+    progress = progress if progress is not None else {}
+    progress["calls"] = lambda: comm.calls
+    progress["phase"] = "communicator attached"
     lo, hi = par.shard_range(n + 8, rank, world)
     ctx.srs_generate_slice(tau, lo, hi - lo, n + 8)
+    progress["phase"] = "SRS slice generated"
     prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    progress["phase"] = "sharded setup done"
     L = fld["fq_limbs"]
     preps = []
     for hw, (pi_pos, pi_vals, blinders) in zip(host_w, pis):
@@ -474,17 +511,20 @@ def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis
         return k, ctx.prove_prepared(preps[k][0], transcript(), preps[k ^ 1][0])
 
     ok = True
-    for _ in range(max(args.warmup, 2)):
+    for i in range(max(args.warmup, 2)):
         k, pr = one()
         ok = ok and pr == refs[k]
+        progress["phase"] = "warm-up proof %d done" % i
     barrier()
     calls0, bytes0 = ctx.comm_stats()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         k, pr = one()
+        progress["phase"] = "timed proof %d done" % i
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     barrier()
+    progress["phase"] = "timed region done"
     ok = ok and pr == refs[k]
     calls1, bytes1 = ctx.comm_stats()
     red_dev = dev if dist.get_backend() == "nccl" else None
@@ -523,6 +563,34 @@ def pmc_traffic(kernel, curve, log_n):
     if best is None:
         return None, None
     return round(best[1]), "profiles/" + best[2]
+
+
+def pmc_valu_busy(kernel, curve, log_n):
+    """VALUBusy of `kernel` from the committed rocprofv3 PMC pass (tools/pmc_valu.sh -> profiles/pmc_valu_*.txt):
+    SQ_ACTIVE_INST_VALU * 4 / (SIMDs * GRBM_GUI_ACTIVE per XCD) -- rocprof's own derived-metric formula, gfx950 has no
+    entry of its own.  Only valid for the default workload."""
+    if curve != "bn254" or log_n != 20:
+        return None, None
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_valu_r*.txt"))):
+        cur, vals = None, {}
+        for line in open(f):
+            if not line.startswith(" "):
+                cur = line.split()[0] if line.strip() else None
+                continue
+            if cur is not None and cur.startswith(kernel):
+                parts = line.split()
+                if len(parts) == 2 and parts[0] in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"):
+                    vals[parts[0]] = float(parts[1])
+        if len(vals) == 2 and vals["GRBM_GUI_ACTIVE"] > 0:
+            key = [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
+            if best is None or key >= best[0]:
+                best = (key, vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * vals["GRBM_GUI_ACTIVE"] / 8.0), os.path.basename(f))
+    if best is None:
+        return None, None
+    return round(best[1], 4), "profiles/" + best[2]
 
 
 def cpu_baseline(ctx, curve, log_n, evals, wires, table, pi, blinders, vk_pts, gpu_proof):

@@ -64,8 +64,12 @@ int zkt_ctx_set_stream(zkt_ctx* ctx, void* hip_stream);
 int zkt_ctx_synchronize(zkt_ctx* ctx);
 /* Timing with HIP events on the stream the kernels run on (each event pair costs a few microseconds of stream time,
  * so only these scopes exist).  Names: "ntt_<log2 size>" (whole transform), "msm_main" (grouping, accumulation and
- * bucket fold of one MSM), "msm_accumulate" (the accumulation kernel alone), "msm_tail" (bucket reduction, on the side
- * stream), "quotient". */
+ * bucket fold of one MSM), "msm_accumulate" (the accumulation kernel alone), "msm_fold" / "msm_tail" (bucket fold and
+ * reduction, on the side stream), "quotient", and the prover's rounds as stream time between their first and last
+ * launch: "round1", "round2" (prove.rs:116-185; issued early when announced by zkt_prove_set_next), "round3"
+ * (:190-255), "round4" (:258-313), "round5" (:318-451).
+ * on = 0: off; 1: every scope; 2: only "msm_accumulate" -- the level for timing the dominant kernel live inside a
+ * throughput measurement (one event pair per MSM instead of ~80 records per proof). */
 int zkt_profile_enable(zkt_ctx* ctx, int on);
 int zkt_profile_get(zkt_ctx* ctx, const char* name, uint64_t* calls, double* total_ms);
 const char* zkt_version(void);

@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import fields as F, curve as C, plonk as P, coracle as K
-from helpers import field_elems, unhex_point
+from helpers import field_elems, unhex_point, run_sharded_ranks, sharded_exchange_bytes
 
 CURVES = [F.BN254, F.BLS12_381]
 
@@ -228,6 +228,52 @@ def test_headline_configs_proof_bytes_equal_cpu_oracle(cvname, log_n, ctxs):
         assert hashlib.sha256(got).hexdigest() == e["proof_sha256"]
     pis = [w["pi"][k] for k in w["pi_pos"]]
     assert P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), pis)
+    if cv.name == "bn254" and log_n == 20:
+        # configs[3]'s proof once more as ONE proof across 2 / 4 / 8 ranks (thread ranks on this GPU: SRS slices, sharded
+        # setup, class transforms of 2^21 / 2^20 / 2^19 points, the quotient exchange): every rank's bytes == the CPU
+        # oracle's.  7 public inputs: evaluated from l1 rotations at world 2 and 4, through the transform at world 8.
+        _sharded_legs(z, cv, n, srs, evals, vk, w, blinders, want, (2, 4, 8))
+
+
+def _sharded_legs(z, cv, n, srs, evals, vk, w, blinders, want, worlds):
+    job = (w["a"], w["b"], w["c"], w["table"], w["pi_pos"], w["pi_vals"], K.fr_to_mont(cv, blinders))
+    for world in worlds:
+        out = run_sharded_ranks(z, cv, n, srs, {"evals": evals}, vk, [job], world)
+        for r in range(world):
+            proofs, (calls, sent), (setup_calls, setup_sent) = out[r]
+            assert proofs == [want], (world, r)
+            assert calls - setup_calls == 5
+            assert sent - setup_sent == sharded_exchange_bytes(cv, n, world, 1), (world, r)
+
+
+def test_sharded_proof_with_many_public_inputs_at_2_20(ctxs):
+    """More than QUOTIENT_PI_DIRECT_MAX (16) public inputs at the headline size: PI(X) goes through the inverse transform
+    and the class transform on every world size (prover.hip `pi_direct` false), single GPU and 4 ranks, against the CPU
+    oracle's array prover on the same SRS, witness and blinders."""
+    import bench as B
+    import zkt_plonk_amd as z
+    from oracle import fastplonk as FP
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    log_n, n = 20, 1 << 20
+    tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
+    ctx.srs_generate(tau, n + 8)
+    circ = B.synthetic_circuit(B.FIELDS[cv.name], log_n, n_public=20, seed=0xB16)
+    evals = {name: K.fr_to_mont(cv, circ["sel"][name]) for name in z.PK_ORDER}
+    srs = ctx.srs_download(0, n + 8)
+    keys = FP.setup(cv, srs, log_n, evals, commitments=True)
+    vk = keys.verifier_key(cv, circ["pi"].keys())
+    gates = circ["gates"]
+    pi_pos = sorted(circ["pi"])
+    assert len(pi_pos) == 20
+    w = dict(a=K.fr_to_mont(cv, circ["a"][:gates]), b=K.fr_to_mont(cv, circ["b"][:gates]),
+             c=K.fr_to_mont(cv, circ["c"][:gates]), table=K.fr_to_mont(cv, circ["table"]), pi=circ["pi"], pi_pos=pi_pos,
+             pi_vals=K.fr_to_mont(cv, [circ["pi"][k] for k in pi_pos]))
+    blinders = field_elems(cv.fr.p, 4040, P.NUM_BLINDERS)
+    want = FP.prove(cv, srs, keys, w["a"], w["b"], w["c"], w["table"], w["pi"], P.new_seeded_transcript(cv, vk), blinders)
+    z.GpuProver.setup(ctx, log_n, evals)
+    assert _gpu_prove_arrays(z, ctx, cv, w, vk, blinders) == want
+    _sharded_legs(z, cv, n, srs, evals, vk, w, blinders, want, (4,))
 
 
 def test_config4_bls12_381_2_22_proof_bytes_equal_cpu_oracle(ctxs):
@@ -245,21 +291,24 @@ def test_config4_bls12_381_2_22_proof_bytes_equal_cpu_oracle(ctxs):
     srs = ctx.srs_download(0, n + 8)
     keys = FP.setup(cv, srs, log_n, evals, commitments=False)
     assert FP.commit(cv, srs, keys.pk["q_c"]) == vk.commits["q_c"]
-    del evals
     blinders = field_elems(cv.fr.p, 2020, P.NUM_BLINDERS)
     proof = _gpu_prove_arrays(z, ctx, cv, w, vk, blinders)
     assert len(proof) == 1010
     want = FP.prove(cv, srs, keys, w["a"], w["b"], w["c"], w["table"], w["pi"], P.new_seeded_transcript(cv, vk), blinders)
-    del keys, srs
+    del keys
     assert proof == want
     pis = [w["pi"][k] for k in w["pi_pos"]]
     assert P.verify(cv, tau, vk, P.proof_deserialize(cv, proof), P.new_seeded_transcript(cv, vk), pis)
     bad = bytearray(proof)
     bad[-40] ^= 1                                   # inside the last evaluation (h2_eval)
     assert not P.verify(cv, tau, vk, P.proof_deserialize(cv, bytes(bad)), P.new_seeded_transcript(cv, vk), pis)
-    # free the 2^22 circuit (tens of GiB of HBM) before the next test loads its own
+    # free the 2^22 circuit (tens of GiB of HBM) before the ranks below (and the next test) load their own
     ctx.srs_generate(tau, 64)
     z.GpuProver(ctx, 3, {k: np.zeros((0, 4), dtype=np.uint64) for k in z.PK_ORDER})
+    # configs[4] as BASELINE.json names it: ONE proof across 8 ranks (thread ranks on this GPU, ~9 GiB of HBM each):
+    # SRS slices of 2^19 powers, sharded setup, class transforms of 2^21 points on the class and on the class of
+    # "omega-next" ((r + 4) mod 8), public inputs through the transform, 64 MiB of quotient exchange per rank.
+    _sharded_legs(z, cv, n, srs, evals, vk, w, blinders, want, (8,))
 
 
 def test_chained_proofs_with_prefetch(ctxs):

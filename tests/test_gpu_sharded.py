@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import fields as F, plonk as P, coracle as K
-from helpers import field_elems, rand_fr
+from helpers import field_elems, rand_fr, run_sharded_ranks, sharded_exchange_bytes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CURVES = [F.BN254, F.BLS12_381]
@@ -58,42 +58,6 @@ def _setup_oracle(cv, cs, tau):
     return n, srs_arr, be, pk, epk, vk
 
 
-def _rank_job(z, par, comm, cv, n, srs_arr, evals, vk, jobs, out, rank, world, use_setup):
-    """What one rank of a sharded prover does: its SRS slice, the circuit (laid out for its class), the proofs."""
-    try:
-        ctx = z.Context(cv.name, 0)
-        ctx.set_comm(comm)
-        lo, hi = par.shard_range(n + 8, rank, world)
-        ctx.srs_load_slice(srs_arr[lo:hi], lo, n + 8)
-        log_n = n.bit_length() - 1
-        if use_setup:
-            prover, commits = z.GpuProver.setup(ctx, log_n, evals["evals"])
-            L = cv.fq.limbs64
-            rinv = pow(1 << (64 * L), -1, cv.fq.p)
-            for name in z.PK_ORDER:
-                xy, inf = commits[name]
-                pt = None if inf else (sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % cv.fq.p,
-                                       sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % cv.fq.p)
-                assert pt == vk.commits[name], name
-        else:
-            z.GpuProver(ctx, log_n, evals["pk"])
-        proofs = []
-        preps = [ctx.prepare_host(*job) for job in jobs]
-        for i, prep in enumerate(preps):
-            tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
-            z.seed_transcript(tr, vk.n, vk.commits)
-            proofs.append(ctx.prove_prepared(prep, tr, preps[i + 1] if i + 1 < len(preps) else None))
-        out[rank] = (proofs, ctx.comm_stats())
-        ctx.close()
-    except BaseException as e:          # a rank that dies must not leave the others waiting at the barrier forever
-        out[rank] = e
-        try:
-            comm.group.barrier.abort()
-        except Exception:
-            pass
-        raise
-
-
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("cvname,gates,table_size", [("bn254", 60, 16), ("bn254", 4000, 1024), ("bls12_381", 1000, 64),
                                                      ("bn254", 60000, 1024)])
@@ -129,21 +93,16 @@ def test_sharded_proof_bytes_equal_the_oracle(world, cvname, gates, table_size):
         a, b_, c = (mont(w) for w in c_.wire_evals(c_.n_gates))
         pos = sorted(c_.pi)
         jobs.append((a, b_, c, mont(c_.table), pos, mont([c_.pi[i] for i in pos]), mont(b)))
-    group = par.LocalGroup(world)
-    out = [None] * world
-    ths = [threading.Thread(target=_rank_job, args=(z, par, group.comm(r), cv, n, srs_arr, {"evals": evals}, vk, jobs, out,
-                                                    r, world, True)) for r in range(world)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join(timeout=600)
+    out = run_sharded_ranks(z, cv, n, srs_arr, {"evals": evals}, vk, jobs, world)
+    xyzz = 4 * cv.fq.limbs64 * 8
     for r in range(world):
-        assert not isinstance(out[r], BaseException) and out[r] is not None, out[r]
-        proofs, (calls, sent) = out[r]
+        proofs, (calls, sent), (setup_calls, setup_sent) = out[r]
         assert proofs == want, r
-        # per proof: 4 partial-sum exchanges + the quotient exchange; setup: 2
+        # setup: the ten VerifierKey commitments in 2 exchanges; per proof: 4 partial-sum exchanges + the quotient exchange,
+        # which moves exactly 4n * 32 / world bytes per rank
+        assert (setup_calls, setup_sent) == (2, 10 * xyzz)
         assert calls == 2 + 5 * len(jobs)
-        assert sent >= len(jobs) * (4 * n // world) * 32
+        assert sent - setup_sent == sharded_exchange_bytes(cv, n, world, len(jobs))
 
 
 def test_two_rank_rehearsal_over_gloo_processes():

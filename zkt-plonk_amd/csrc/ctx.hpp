@@ -39,7 +39,7 @@ struct zkt_ctx {
     size_t io_b_bytes = 0;
 
     // optional per-kernel HIP-event timing (bench.py's live roofline measurement)
-    bool prof_on = false;
+    int prof_on = 0;   // 0 off, 1 every scope, 2 only the dominant kernel's scope ("msm_accumulate")
     struct ProfSlot {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
         double total_ms = 0.0;
@@ -82,7 +82,8 @@ struct ProfScope {
     zkt_ctx::ProfSlot* slot = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t stream = nullptr;
-    ProfScope(zkt_ctx* ctx, const char* name, hipStream_t on_stream = nullptr);
+    uint64_t count = 1;   // units the scope stands for (a batch of transforms is counted per transform)
+    ProfScope(zkt_ctx* ctx, const char* name, hipStream_t on_stream = nullptr, uint64_t units = 1);
     ~ProfScope();
 };
 
@@ -101,6 +102,9 @@ template <class P>
 Fe<P> root_of_unity(int log_n);
 // coset: 0 none, 1 the generator g, ntt_class_code(log_big, cls) a class of a larger coset (see ntt.hip)
 int ntt_run(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out);
+// nb <= NTT_MAX_BATCH transforms of one plan, one launch per pass; distinct outputs, out[y] == in[y] allowed
+int ntt_run_batch(zkt_ctx* c, int log_n, int inverse, int coset, int nb, const void* const* d_in, const size_t* in_len,
+                  void* const* d_out);
 int ntt_class_code(int log_big, int cls);
 int ntt_run_class(zkt_ctx* c, int log_n, int log_big, int cls, const void* d_in, size_t in_len, void* d_out, void* d_fold);
 

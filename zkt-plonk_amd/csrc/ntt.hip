@@ -171,8 +171,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     __shared__ uint32_t lds_w_top[W_UNPACKED ? R / 2 : 1];
 
     const int tid = threadIdx.x;
-    const Fe<P>* in = reinterpret_cast<const Fe<P>*>(a.in);
-    Fe<P>* out = reinterpret_cast<Fe<P>*>(a.out);
+    // blockIdx.y = polynomial of the batch (uniform: scalar selects, no indexed access to the kernel arguments)
+    const uint32_t py = blockIdx.y;
+    const void* in_p = py == 0 ? a.in[0] : py == 1 ? a.in[1] : py == 2 ? a.in[2] : a.in[3];
+    void* out_p = py == 0 ? a.out[0] : py == 1 ? a.out[1] : py == 2 ? a.out[2] : a.out[3];
+    const uint64_t in_len = py == 0 ? a.in_len[0] : py == 1 ? a.in_len[1] : py == 2 ? a.in_len[2] : a.in_len[3];
+    if (a.in_raw) in_p = reinterpret_cast<const char*>(a.in[0]) + (uint64_t)py * 36u * a.raw_n;
+    if (a.out_raw) out_p = reinterpret_cast<char*>(a.out[0]) + (uint64_t)py * 36u * a.raw_n;
+    const Fe<P>* in = reinterpret_cast<const Fe<P>*>(in_p);
+    Fe<P>* out = reinterpret_cast<Fe<P>*>(out_p);
     const Fe<P>* w_inner = reinterpret_cast<const Fe<P>*>(a.w_inner);
     const Fe<P>* in_row = reinterpret_cast<const Fe<P>*>(a.in_row);
     const Fe<P>* tw = reinterpret_cast<const Fe<P>*>(a.tw);
@@ -225,14 +232,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
         uint64_t g = in_base + (uint64_t)r * ld_r + (uint64_t)c * ld_c;
         Fx<P> x;
         if (a.in_raw) {
-            const uint4* rlo = reinterpret_cast<const uint4*>(a.in);
+            const uint4* rlo = reinterpret_cast<const uint4*>(in_p);
             x = tile_get<P>(rlo, rlo + a.raw_n, reinterpret_cast<const uint32_t*>(rlo + 2 * a.raw_n), (int64_t)g);
         } else {
-            x = (g < a.in_len) ? fx_unpack<P>(fe_load<P>(in + g)) : fx_zero<P>();
+            x = (g < in_len) ? fx_unpack<P>(fe_load<P>(in + g)) : fx_zero<P>();
         }
         // the prover's coset transforms are fed n + 8 coefficients on a domain of 4n: three rows in four are padding,
         // and whole wavefronts see nothing but padding (a wave covers consecutive rows), so the branch is uniform
-        if (in_row && (a.in_raw || g < a.in_len)) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(in_row + r)));
+        if (in_row && (a.in_raw || g < in_len)) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(in_row + r)));
         if (tw) {
             uint64_t ti = LAST ? (tw_base + ((uint64_t)c << LOG_R) + r) : (tw_base + r);
             x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(tw + ti)));
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
         if (out_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(out_row + k)));
         const uint64_t at = out_base + (uint64_t)k * st_k + c;
         if (a.out_raw) {
-            uint4* rlo = reinterpret_cast<uint4*>(a.out);
+            uint4* rlo = reinterpret_cast<uint4*>(out_p);
             tile_put<P>(rlo, rlo + a.raw_n, reinterpret_cast<uint32_t*>(rlo + 2 * a.raw_n), (int64_t)at, x);
         } else {
             fe_store<P>(out + at, fx_pack<P>(fx_cond_sub_p<P>(x)));
@@ -528,25 +535,32 @@ static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>&
 }
 
 template <class P, bool LAST>
-static void launch_pass(zkt_ctx* c, int log_r, unsigned blocks, const NttPassArgs& a) {
+static void launch_pass(zkt_ctx* c, int log_r, unsigned blocks, unsigned nb, const NttPassArgs& a) {
+    const dim3 grid(blocks, nb);
     switch (log_r) {
-        case 5: hipLaunchKernelGGL((k_ntt_pass<P, 5, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
-        case 6: hipLaunchKernelGGL((k_ntt_pass<P, 6, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
-        case 7: hipLaunchKernelGGL((k_ntt_pass<P, 7, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((k_ntt_pass<P, 8, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL((k_ntt_pass<P, 9, LAST>), dim3(blocks), dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 5: hipLaunchKernelGGL((k_ntt_pass<P, 5, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 6: hipLaunchKernelGGL((k_ntt_pass<P, 6, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 7: hipLaunchKernelGGL((k_ntt_pass<P, 7, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_ntt_pass<P, 8, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((k_ntt_pass<P, 9, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
     }
 }
 
+// nb <= NTT_MAX_BATCH transforms of the same plan, one launch per pass (gridDim.y = polynomial): the prover's rounds
+// transform two or three polynomials at a time (prove.rs:120-122,166-167; quotient_poly.rs:52-96), and a 2^20
+// transform alone is a single wave of workgroups whose ramp and tail are a third of its time.
 template <class P>
-static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
+static int ntt_run_batch_t(zkt_ctx* c, int log_n, int inverse, int coset, int nb, const void* const* d_in, const size_t* in_len,
+                           void* const* d_out) {
+    if (nb < 1 || nb > NTT_MAX_BATCH) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "transform batch out of range");
     if (log_n < 0 || log_n > P::TWO_ADICITY)
         return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE,
                        "InvalidEvalDomainSize: log_size_of_group " + std::to_string(log_n) + " exceeds adicity " +
                            std::to_string(P::TWO_ADICITY));
     if (log_n > 27) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "domains above 2^27 are not supported");
     const uint64_t N = (uint64_t)1 << log_n;
-    if (in_len > N) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "more coefficients than the domain size");
+    for (int y = 0; y < nb; ++y)
+        if (in_len[y] > N) return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "more coefficients than the domain size");
     auto key = std::make_tuple(log_n, inverse ? 1 : 0, coset);
     auto it = c->ntt_plans.find(key);
     if (it == c->ntt_plans.end()) {
@@ -557,15 +571,16 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
     }
     const NttPlan<P>& pl = *static_cast<const NttPlan<P>*>(it->second.get());
     const std::string prof_name = "ntt_" + std::to_string(log_n);  // e.g. "ntt_20", "ntt_22"
-    ProfScope prof_all(c, prof_name.c_str());
+    ProfScope prof_all(c, prof_name.c_str(), nullptr, nb);          // counted per transform
     if (pl.npass == 0) {
-        hipLaunchKernelGGL(k_ntt_small<P>, dim3(1), dim3(NTT_THREADS), 0, c->stream, (const Fe<P>*)d_in,
-                           (uint64_t)in_len, (Fe<P>*)d_out, log_n, (const Fe<P>*)pl.small_w,
-                           (const Fe<P>*)pl.small_in, (const Fe<P>*)pl.small_out);
+        for (int y = 0; y < nb; ++y)
+            hipLaunchKernelGGL(k_ntt_small<P>, dim3(1), dim3(NTT_THREADS), 0, c->stream, (const Fe<P>*)d_in[y],
+                               (uint64_t)in_len[y], (Fe<P>*)d_out[y], log_n, (const Fe<P>*)pl.small_w,
+                               (const Fe<P>*)pl.small_in, (const Fe<P>*)pl.small_out);
         ZKT_HIP(c, hipGetLastError());
         return 0;
     }
-    int rc = ensure_buffer(c, &c->ntt_scratch, &c->ntt_scratch_bytes, N * 36);   // raw limbs between passes
+    int rc = ensure_buffer(c, &c->ntt_scratch, &c->ntt_scratch_bytes, N * 36 * (size_t)nb);   // raw limbs between passes
     if (rc) return rc;
     const int p = pl.npass;
     const unsigned blocks = (unsigned)(N >> TILE_LOG);
@@ -573,13 +588,16 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
     for (int i = 0; i < p; ++i) {
         NttPassArgs a{};
         const bool last = (i == p - 1);
-        a.in = (i == 0) ? d_in : c->ntt_scratch;
-        a.out = last ? d_out : c->ntt_scratch;
+        for (int y = 0; y < NTT_MAX_BATCH; ++y) {
+            const int yy = y < nb ? y : 0;
+            a.in[y] = (i == 0) ? d_in[yy] : c->ntt_scratch;
+            a.out[y] = last ? d_out[yy] : c->ntt_scratch;
+            a.in_len[y] = (i == 0) ? (uint64_t)in_len[yy] : N;
+        }
         a.w_inner = pl.w_inner[i];
         a.in_row = (i == 0) ? pl.in_row : nullptr;
         a.tw = pl.tw[i];
         a.out_row = last ? pl.out_row : nullptr;
-        a.in_len = (i == 0) ? (uint64_t)in_len : N;
         a.log_n = (uint32_t)log_n;
         a.in_raw = (i == 0) ? 0u : 1u;
         a.out_raw = last ? 0u : 1u;
@@ -587,15 +605,26 @@ static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* 
         acc += pl.log_r[i];
         if (!last) {
             a.log_s = (uint32_t)(log_n - acc);
-            launch_pass<P, false>(c, pl.log_r[i], blocks, a);
+            launch_pass<P, false>(c, pl.log_r[i], blocks, (unsigned)nb, a);
         } else {
             a.log_r1 = (uint32_t)pl.log_r[0];
             a.log_mid = (uint32_t)(log_n - pl.log_r[0] - pl.log_r[i]);
-            launch_pass<P, true>(c, pl.log_r[i], blocks, a);
+            launch_pass<P, true>(c, pl.log_r[i], blocks, (unsigned)nb, a);
         }
         ZKT_HIP(c, hipGetLastError());
     }
     return 0;
+}
+
+template <class P>
+static int ntt_run_t(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {
+    return ntt_run_batch_t<P>(c, log_n, inverse, coset, 1, &d_in, &in_len, &d_out);
+}
+
+int ntt_run_batch(zkt_ctx* c, int log_n, int inverse, int coset, int nb, const void* const* d_in, const size_t* in_len,
+                  void* const* d_out) {
+    if (c->curve == ZKT_CURVE_BN254) return ntt_run_batch_t<Bn254Fr>(c, log_n, inverse, coset, nb, d_in, in_len, d_out);
+    return ntt_run_batch_t<Bls381Fr>(c, log_n, inverse, coset, nb, d_in, in_len, d_out);
 }
 
 int ntt_run(zkt_ctx* c, int log_n, int inverse, int coset, const void* d_in, size_t in_len, void* d_out) {

@@ -20,14 +20,16 @@
 
 namespace zkt {
 
+constexpr int NTT_MAX_BATCH = 4;   // transforms of one plan issued as ONE launch per pass (gridDim.y = polynomial)
+
 struct NttPassArgs {
-    const void* in;        // Fe*
-    void* out;             // Fe*
+    const void* in[NTT_MAX_BATCH];    // Fe* (raw passes: polynomial y lives at in[0] + y * 36 * raw_n bytes)
+    void* out[NTT_MAX_BATCH];         // Fe*
     const void* w_inner;   // R/2 inner twiddles W_R^j
     const void* in_row;    // optional R-entry input row scale (forward coset, pass 1)
     const void* tw;        // optional boundary twiddles (row-shared or tile-shaped)
     const void* out_row;   // optional R-entry output row scale (inverse coset, last pass)
-    uint64_t in_len;       // elements of `in` that exist (rest read as zero); pass 1 only
+    uint64_t in_len[NTT_MAX_BATCH];   // elements of `in` that exist (rest read as zero); pass 1 only
     uint32_t log_n;
     uint32_t log_s;        // non-last: log2 of the inner stride S (columns); last: unused
     uint32_t log_r1;       // last: log2 R1

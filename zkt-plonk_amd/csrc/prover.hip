@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <optional>
 #include <vector>
 
 namespace zkt {
@@ -74,6 +75,8 @@ struct CircuitState {
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
+    hipStream_t copy_stream = nullptr;   // host witness uploads travel beside the main stream's work (cold path)
+    hipEvent_t ev_copy[4] = {};          // a, b, c uploaded; [3]: main stream reached the upload point
     void* pinned_pi = nullptr;      // host staging of pi_tab
     uint32_t* pi_tab = nullptr;     // device: QUOTIENT_PI_DIRECT_MAX entries of {rotation, 9 limbs}
     void* eval_pw = nullptr;        // EVAL_MAX x 257 powers of the evaluation points (round 5)
@@ -226,19 +229,41 @@ struct Prover {
         return ZKT_OK;
     }
 
-    // iNTT of n evaluations into a zero-tailed coefficient buffer, trim, blind (prove.rs:120-127 etc.)
-    int evals_to_blinded_poly(const void* ev, void* poly, int blinder_off, int k, int len_slot) {
+    // iNTT of n evaluations into a zero-tailed coefficient buffer, trim, blind (prove.rs:120-127 etc.); the polynomials
+    // of one round go through the transform as ONE batch (one launch per pass)
+    struct PolyJob {
+        const void* ev;
+        void* poly;
+        int blinder_off, k, len_slot;
+    };
+    int evals_to_blinded_polys(const PolyJob* jobs, int nb) {
         const size_t n = S.n;
         int rc;
-        if ((rc = ntt_run(c, S.log_n, 1, 0, ev, n, poly))) return rc;
-        if (k > 0) {
-            if ((rc = poly_trim_len(c, poly, n, S.status + 8 + len_slot, (char*)poly + n * 32, 8))) return rc;
-            if ((rc = poly_add_blinders(c, poly, S.status + 8 + len_slot, (const char*)S.small + (size_t)blinder_off * 32, k, n + 8)))
-                return rc;
-        } else {
-            ZKT_HIP(c, hipMemsetAsync((char*)poly + n * 32, 0, 8 * 32, c->stream));
+        const void* ins[NTT_MAX_BATCH];
+        void* outs[NTT_MAX_BATCH];
+        size_t lens[NTT_MAX_BATCH];
+        for (int y = 0; y < nb; ++y) {
+            ins[y] = jobs[y].ev;
+            outs[y] = jobs[y].poly;
+            lens[y] = n;
+        }
+        if ((rc = ntt_run_batch(c, S.log_n, 1, 0, nb, ins, lens, outs))) return rc;
+        for (int y = 0; y < nb; ++y) {
+            void* poly = jobs[y].poly;
+            if (jobs[y].k > 0) {
+                if ((rc = poly_trim_len(c, poly, n, S.status + 8 + jobs[y].len_slot, (char*)poly + n * 32, 8))) return rc;
+                if ((rc = poly_add_blinders(c, poly, S.status + 8 + jobs[y].len_slot,
+                                            (const char*)S.small + (size_t)jobs[y].blinder_off * 32, jobs[y].k, n + 8)))
+                    return rc;
+            } else {
+                ZKT_HIP(c, hipMemsetAsync((char*)poly + n * 32, 0, 8 * 32, c->stream));
+            }
         }
         return ZKT_OK;
+    }
+    int evals_to_blinded_poly(const void* ev, void* poly, int blinder_off, int k, int len_slot) {
+        const PolyJob j{ev, poly, blinder_off, k, len_slot};
+        return evals_to_blinded_polys(&j, 1);
     }
 
     int check_status() {
@@ -350,6 +375,28 @@ struct Prover {
         return ntt_run_class(c, S.log_m, S.log_n + 2, (S.cls + 4) & 7, S.poly[coset_src[k]], S.n + 8, S.wnext[next_of[k]], S.fold);
     }
 
+    // several witness polynomials onto the 4n coset in one launch per pass (single GPU; a sharded proof transforms its
+    // classes one by one)
+    int to_coset_many(std::initializer_list<int> ks) {
+        static const int coset_src[W_COUNT] = {0, 1, 2, 8, 6, 7, 3, 4, 5};  // a b c pi z1 z2 t h1 h2
+        int rc;
+        if (S.G != 1 || ks.size() > (size_t)NTT_MAX_BATCH) {
+            for (int k : ks) if ((rc = to_coset(k))) return rc;
+            return ZKT_OK;
+        }
+        const void* ins[NTT_MAX_BATCH];
+        void* outs[NTT_MAX_BATCH];
+        size_t lens[NTT_MAX_BATCH];
+        int nb = 0;
+        for (int k : ks) {
+            ins[nb] = S.poly[coset_src[k]];
+            outs[nb] = S.wcos[k];
+            lens[nb] = S.n + 8;
+            ++nb;
+        }
+        return nb ? ntt_run_batch(c, S.log_n + 2, 0, 1, nb, ins, lens, outs) : ZKT_OK;
+    }
+
     void swap_work_sets() {   // current <-> alternate copies of what early work of the next proof overwrites
         for (int k = 0; k < 3; ++k) std::swap(S.poly[k], S.poly_alt[k]);
         std::swap(S.status, S.status_alt);
@@ -360,6 +407,7 @@ struct Prover {
     int enqueue_round_1(const zkt_prove_inputs& in) {
         const size_t n = S.n;
         int rc;
+        ProfScope prof_round(c, "round1");
         if (in.n_rows > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "more rows than the circuit bound");
         if (in.table_len >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "max table size is equal or larger than n");
         if (n < 8) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "circuit bound below 8");
@@ -389,50 +437,79 @@ struct Prover {
                 }
             }
         }
-        for (int k = 0; k < 3; ++k) {
-            if (from_vars) {
-                if ((rc = poly_gather_pad(c, d_vars, in.n_vars, d_idx[k], in.n_rows, S.ev[k], n, S.status))) return rc;
-            } else if (in.wires_on_device) {
-                if ((rc = poly_copy_pad(c, wires[k], in.n_rows, S.ev[k], n))) return rc;   // prove.rs:39-55 pad_to
-            } else {
-                ZKT_HIP(c, hipMemsetAsync(S.ev[k], 0, n * 32, c->stream));
+        const bool host_wires = !from_vars && !in.wires_on_device;
+        if (host_wires) {
+            // cold path: the three wire vectors cross PCIe inside the call.  They travel on the copy stream while the main
+            // stream already transforms and commits the wire before, so only the first upload is exposed.
+            ZKT_HIP(c, hipEventRecord(S.ev_copy[3], c->stream));       // the targets are free once earlier work has drained
+            ZKT_HIP(c, hipStreamWaitEvent(S.copy_stream, S.ev_copy[3], 0));
+            for (int k = 0; k < 3; ++k) {
+                if (in.n_rows < n)
+                    ZKT_HIP(c, hipMemsetAsync((char*)S.ev[k] + in.n_rows * 32, 0, (n - in.n_rows) * 32, S.copy_stream));
                 if (in.n_rows)
-                    ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32, hipMemcpyHostToDevice, c->stream));
+                    ZKT_HIP(c, hipMemcpyAsync(S.ev[k], wires[k], in.n_rows * 32, hipMemcpyHostToDevice, S.copy_stream));
+                ZKT_HIP(c, hipEventRecord(S.ev_copy[k], S.copy_stream));
+                ZKT_HIP(c, hipStreamWaitEvent(c->stream, S.ev_copy[k], 0));
+                if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
+                if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
             }
-            if ((rc = evals_to_blinded_poly(S.ev[k], S.poly[k], 2 * k, 2, k))) return rc;
+        } else {
+            for (int k = 0; k < 3; ++k) {
+                if (from_vars) {
+                    if ((rc = poly_gather_pad(c, d_vars, in.n_vars, d_idx[k], in.n_rows, S.ev[k], n, S.status))) return rc;
+                } else {
+                    if ((rc = poly_copy_pad(c, wires[k], in.n_rows, S.ev[k], n))) return rc;   // prove.rs:39-55 pad_to
+                }
+            }
+            const PolyJob jobs[3] = {{S.ev[0], S.poly[0], 0, 2, 0}, {S.ev[1], S.poly[1], 2, 2, 1}, {S.ev[2], S.poly[2], 4, 2, 2}};
+            if ((rc = evals_to_blinded_polys(jobs, 3))) return rc;
+            for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
         }
-        for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
-        for (int k : {W_A, W_B, W_C}) if ((rc = to_coset(k))) return rc;
-        return ZKT_OK;
+        return to_coset_many({W_A, W_B, W_C});
     }
 
     // ---- round 2 (prove.rs:145-185): its three commitments join the batch of round 1
-    int enqueue_round_2(const zkt_prove_inputs& in, bool* same_table_out) {
-        const size_t n = S.n;
-        int rc;
+    // The table polynomial's part of round 2 (prove.rs:145-156,178-180): evaluations, coefficients, commitment, coset.
+    // It depends on nothing but the lookup table, so a direct (unannounced) proof issues it FIRST: it then covers the
+    // upload of the first wire vector of a cold proof.  Returns whether the resident table polynomial is reused.
+    bool table_is_cached(const zkt_prove_inputs& in) const {
         // the cached commitment belongs to the SRS it was made under: a reloaded key invalidates it (the polynomial and
         // its coset would survive, but one flag keeps the three together)
-        const bool same_table = S.t_cached && S.t_srs_generation == c->srs_generation &&
-                                S.cached_table.size() == 4 * in.table_len &&
-                                (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
+        return S.t_cached && S.t_srs_generation == c->srs_generation && S.cached_table.size() == 4 * in.table_len &&
+               (in.table_len == 0 || memcmp(S.cached_table.data(), in.table, in.table_len * 32) == 0);
+    }
+    int enqueue_table(const zkt_prove_inputs& in, bool with_coset) {
+        const size_t n = S.n;
+        int rc;
+        if (in.table_len >= n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "max table size is equal or larger than n");
+        S.t_cached = false;
+        S.t_coset_valid = false;
+        ZKT_HIP(c, hipMemsetAsync(S.ev[3], 0, n * 32, c->stream));
+        if (in.table_len) ZKT_HIP(c, hipMemcpyAsync(S.ev[3], in.table, in.table_len * 32, hipMemcpyHostToDevice, c->stream));
+        if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;      // t: no blinders
+        if ((rc = commit_begin(S.poly[3], n, 3))) return rc;
+        if (with_coset && (rc = to_coset(W_T))) return rc;
+        return ZKT_OK;
+    }
+
+    // table_done: enqueue_table has already run for this proof (direct path)
+    int enqueue_round_2(const zkt_prove_inputs& in, bool* same_table_out, bool table_done = false) {
+        const size_t n = S.n;
+        int rc;
+        ProfScope prof_round(c, "round2");
+        const bool same_table = !table_done && table_is_cached(in);
         *same_table_out = same_table;
-        if (!same_table) {
-            S.t_cached = false;
-            S.t_coset_valid = false;
-            ZKT_HIP(c, hipMemsetAsync(S.ev[3], 0, n * 32, c->stream));
-            if (in.table_len) ZKT_HIP(c, hipMemcpyAsync(S.ev[3], in.table, in.table_len * 32, hipMemcpyHostToDevice, c->stream));
-            if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;      // t: no blinders
-        }
+        if (!same_table && !table_done && (rc = enqueue_table(in, false))) return rc;
         if ((rc = poly_mul_vec(c, S.q_lookup_ev, S.ev[2], S.ev[4], n))) return rc;         // f = q_lookup . c
         if ((rc = combine_split(in.table, in.table_len, !same_table))) return rc;
-        if ((rc = evals_to_blinded_poly(S.ev[5], S.poly[4], 6, 3, 4))) return rc;          // h1: 3 blinders
-        if ((rc = evals_to_blinded_poly(S.ev[6], S.poly[5], 9, 2, 5))) return rc;          // h2: 2 blinders
-        if (!same_table && (rc = commit_begin(S.poly[3], n, 3))) return rc;
+        {
+            const PolyJob jobs[2] = {{S.ev[5], S.poly[4], 6, 3, 4}, {S.ev[6], S.poly[5], 9, 2, 5}};   // h1: 3 blinders, h2: 2
+            if ((rc = evals_to_blinded_polys(jobs, 2))) return rc;
+        }
         if ((rc = commit_begin(S.poly[4], n + 3, 4))) return rc;
         if ((rc = commit_begin(S.poly[5], n + 2, 5))) return rc;
-        if (!S.t_coset_valid && (rc = to_coset(W_T))) return rc;   // unchanged table: its coset is still resident
-        for (int k : {W_H1, W_H2}) if ((rc = to_coset(k))) return rc;
-        return ZKT_OK;
+        if (!S.t_coset_valid && !table_done) return to_coset_many({W_T, W_H1, W_H2});
+        return to_coset_many({W_H1, W_H2});   // unchanged table: its coset is still resident
     }
 
     int run(const zkt_prove_inputs& in, std::vector<uint8_t>& proof) {
@@ -447,8 +524,12 @@ struct Prover {
             S.prefetch_stage = 0;
         } else {
             S.prefetch_stage = 0;
+            // nobody announced this proof: a fresh lookup table's polynomial goes first (it waits for nothing, and its
+            // commitment covers the first wire upload of a cold proof)
+            const bool table_first = !table_is_cached(in);
+            if (table_first && (rc = enqueue_table(in, true))) return rc;
             if ((rc = enqueue_round_1(in))) return rc;
-            if ((rc = enqueue_round_2(in, &same_table))) return rc;
+            if ((rc = enqueue_round_2(in, &same_table, table_first))) return rc;
         }
 
         // prove.rs:110 -- public inputs (BTreeMap order = ascending position)
@@ -498,6 +579,8 @@ struct Prover {
         void* pn2 = S.wcos[W_Z1];
         void* sd2 = (char*)S.wcos[W_Z1] + n * 32;
         mark("challenges round 3");
+        std::optional<ProfScope> prof_round;   // stream time of a round, first launch to last (zkt_profile_get "round3" ...)
+        prof_round.emplace(c, "round3");
         if ((rc = z1_terms(c, za))) return rc;
         if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;   // PN
         if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;    // SD
@@ -516,13 +599,13 @@ struct Prover {
             const F inv12 = fe_inv_host<R>(fe_mul<R>(d1, d2));
             const F inv1 = fe_mul<R>(inv12, d2), inv2 = fe_mul<R>(inv12, d1);
             if ((rc = z_combine(c, S.sc[2], S.sc[3], inv1.v, S.ev[7], n))) return rc;
-            if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[6], 11, 3, 6))) return rc;     // z1: 3 blinders
-            if ((rc = z_combine(c, pn2, sd2, inv2.v, S.ev[7], n))) return rc;
-            if ((rc = evals_to_blinded_poly(S.ev[7], S.poly[7], 14, 3, 7))) return rc;     // z2: 3 blinders
+            if ((rc = z_combine(c, pn2, sd2, inv2.v, S.sc[0], n))) return rc;              // num / den are free again
+            const PolyJob jobs[2] = {{S.ev[7], S.poly[6], 11, 3, 6}, {S.sc[0], S.poly[7], 14, 3, 7}};   // z1, z2: 3 blinders each
+            if ((rc = evals_to_blinded_polys(jobs, 2))) return rc;
         }
         if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
         if ((rc = commit_begin(S.poly[7], n + 3, 1))) return rc;
-        for (int k : {W_Z1, W_Z2}) if ((rc = to_coset(k))) return rc;
+        if ((rc = to_coset_many({W_Z1, W_Z2}))) return rc;
         // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well.  With a handful of
         // public inputs it is never built: the quotient kernel evaluates it from rotations of l1 (poly.hpp).
         for (size_t i = 0; i < in.n_pi; ++i)
@@ -549,12 +632,14 @@ struct Prover {
             static const int slots[2] = {0, 1};
             if ((rc = commit_collect(slots, nullptr, 2, cm + 6))) return rc;
         }
+        prof_round.reset();
         tr_commit("z1_commit", cm[6]);
         tr_commit("z2_commit", cm[7]);
         mark("round 3 finish + commits");
 
         // ---- round 4 (prove.rs:258-313) ----
         const F alpha = tr_challenge("alpha");
+        prof_round.emplace(c, "round4");
         {
             S.t_coset_valid = S.t_cached;
             QuotientArgs q{};
@@ -604,6 +689,7 @@ struct Prover {
             static const int slots[3] = {8, 9, 10};
             if ((rc = commit_collect(slots, nullptr, 3, cm + 8))) return rc;
         }
+        prof_round.reset();
         tr_commit("q_lo_commit", cm[8]);
         tr_commit("q_mid_commit", cm[9]);
         tr_commit("q_hi_commit", cm[10]);
@@ -611,6 +697,7 @@ struct Prover {
 
         // ---- round 5 (prove.rs:318-451, linearization_poly.rs:19-121) ----
         const F xi = tr_challenge("xi");
+        prof_round.emplace(c, "round5");
         F w;
         {
             Fe<R> g = root_of_unity<R>(log_n);
@@ -759,6 +846,7 @@ struct Prover {
                 saw = w2[1];
             }
         }
+        prof_round.reset();
 
         // ---- Proof (proof.rs:106-155), CanonicalSerialize ----
         proof.clear();
@@ -783,6 +871,7 @@ void circuit_release(zkt_ctx* c) {
     if (!c->circuit) return;
     (void)hipStreamSynchronize(c->stream);
     CircuitState& S = *c->circuit;
+    if (S.copy_stream) (void)hipStreamSynchronize(S.copy_stream);
     auto fr = [&](void* p) { dev_free(c, p); };
     for (void* p : S.pk) fr(p);
     for (void* p : S.coset) fr(p);
@@ -800,6 +889,11 @@ void circuit_release(zkt_ctx* c) {
     fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
     if (S.pinned) (void)hipHostFree(S.pinned);
     if (S.pinned_pi) (void)hipHostFree(S.pinned_pi);
+    if (S.copy_stream) {
+        (void)hipStreamSynchronize(S.copy_stream);
+        (void)hipStreamDestroy(S.copy_stream);
+    }
+    for (auto e : S.ev_copy) if (e) (void)hipEventDestroy(e);
     c->circuit.reset();
 }
 
@@ -868,6 +962,8 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     if ((rc = dev_alloc(c, (void**)&S.lk_u32, 5 * S.lk_cap * 4 + 16))) return rc;
     if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
+    ZKT_HIP(c, hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
+    for (auto& e : S.ev_copy) ZKT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
     if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * (257 + eval_blocks)))) return rc;
@@ -1091,11 +1187,17 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
     if (c->curve == ZKT_CURVE_BN254) {
         Prover<Bn254Curve> p(c, *c->circuit, tr);
         rc = p.run(*in, proof);
-        if (rc) (void)hipStreamSynchronize(c->stream);   // an early return may leave staged copies in flight
+        if (rc) {   // an early return may leave staged copies in flight
+            (void)hipStreamSynchronize(c->circuit->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
     } else {
         Prover<Bls381Curve> p(c, *c->circuit, tr);
         rc = p.run(*in, proof);
-        if (rc) (void)hipStreamSynchronize(c->stream);
+        if (rc) {
+            (void)hipStreamSynchronize(c->circuit->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
     }
     if (rc) {
         // a failed proof withdraws the announcement of its successor: the next call must not issue early work from
