@@ -329,6 +329,35 @@ def main():
                    "unchained_single_proof_ms": round(min(warm), 3),
                    "unchained_is": "witness in HBM, table cached, no announcement; min of 3"}
 
+    # ---- the verifier the reference's caller runs after every proof (bin/src/main.rs:298; proof.rs:285-503): host C++,
+    # ---- pairings included (zkt_verify), on the proof just made -----------------------------------------------------
+    verify = None
+    if rank == 0:
+        from zkt_plonk_amd import _lib as zl
+        pi_pos, pi_vals, _bl = pis[0]
+        vproof = ctx.prove_prepared(preps[0], transcript())
+        w_n = pow(fld["gen"], (fld["r"] - 1) >> log_n, fld["r"])
+        roots = fr_to_mont_gpu(ctx, fld, [pow(w_n, i, fld["r"]) for i in pi_pos])
+        vk_xy = np.stack([np.zeros(2 * L, dtype=np.uint64) if commits[name][1] else np.asarray(commits[name][0], dtype=np.uint64)
+                          for name in z.PK_ORDER])
+        vk_inf = [bool(commits[name][1]) for name in z.PK_ORDER]
+        g_xy = ctx.srs_download(0, 1)[0]
+        h2, bh2 = zl.srs_generate_g2(args.curve, tau)
+
+        def run_verify(raw):
+            t = time.perf_counter()
+            ok = zl.verify(args.curve, n, vk_xy, vk_inf, roots, pi_vals, raw, g_xy, h2, bh2, transcript())
+            return ok, 1e3 * (time.perf_counter() - t)
+
+        runs = [run_verify(vproof) for _ in range(7)]
+        bad = bytearray(vproof)
+        bad[-40] ^= 1
+        verify = {"ms": round(sorted(r[1] for r in runs)[len(runs) // 2], 3), "accepted": all(r[0] for r in runs),
+                  "tampered_rejected": not run_verify(bytes(bad))[0],
+                  "is": "zkt_verify on the GPU proof: deserialisation with subgroup checks, transcript, two short G1 "
+                        "multi-scalar multiplications, one folded product of two optimal-ate pairings; one host core, "
+                        "median of 7"}
+
     # ---- roofline of the dominant kernel (MSM bucket accumulation), live HIP-event timing ----
     acc_calls, acc_ms = prof["msm_accumulate"]
     msm_points = n + 3                                              # typical MSM length of the prover
@@ -411,6 +440,9 @@ def main():
     }
     if latency is not None:
         out["latency"] = latency
+    if verify is not None:
+        out["verify_ms"] = verify["ms"]
+        out["verify"] = verify
 
     # ---- ONE proof across all the GPUs (SURVEY.md 8e / BASELINE.json configs[4]) -------------------------------------
     if world > 1 and args.shard != "proofs":

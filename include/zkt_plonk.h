@@ -143,6 +143,10 @@ int zkt_srs_load_dev(zkt_ctx* ctx, const void* d_g1_xy_mont, size_t count);
  * Stands in for PC::setup (ark-poly-commit kzg10 setup), which is out of scope; insecure by design. */
 int zkt_srs_generate(zkt_ctx* ctx, const uint64_t* tau_canonical4, size_t count);
 int zkt_srs_download(zkt_ctx* ctx, size_t offset, size_t count, uint64_t* out_xy_mont);
+/* The G2 half of that test SRS, i.e. SonicKZG10's VerifierKey::h and ::beta_h for the same trapdoor: h = the G2
+ * generator of ark-bn254 / ark-bls12-381, beta_h = tau h (arkworks' Fp2 layout x.c0, x.c1, y.c0, y.c1, Montgomery
+ * limbs).  Host-only; what zkt_verify takes next to the proof.  Insecure by design, like zkt_srs_generate. */
+int zkt_srs_generate_g2(int curve_id, const uint64_t* tau_canonical4, uint64_t* out_h, uint64_t* out_beta_h);
 /* Sharded committer key: this rank keeps powers [offset, offset + count) of a key of `total` powers -- its
  * zkt_shard_range(total, rank, world).  The window table shrinks by the number of ranks.  zkt_msm_g1* then index into the
  * slice; zkt_prove / zkt_circuit_setup combine the ranks' partial sums through the communicator. */
@@ -309,13 +313,18 @@ int zkt_verify_prepare(int curve_id, const zkt_verify_inputs* in, zkt_transcript
                        int* out_is_infinity);
 
 /* The pairing check itself, on the host: prod_i e(P_i, Q_i) == 1 for P_i in G1 ((x, y) Montgomery limbs) and Q_i in G2
- * (arkworks' Fp2 layout: x.c0, x.c1, y.c0, y.c1; all-zero = infinity).  The reduced Tate pairing is computed, not
- * arkworks' optimal ate: the two are powers of one another with an exponent prime to r, so "is the product one" has the
- * same answer (csrc/pairing.hpp).  ~5 ms per pairing.  Points off the curve / twist -> ZKT_ERR_INVALID_ARGUMENT; G2
+ * (arkworks' Fp2 layout: x.c0, x.c1, y.c0, y.c1; all-zero = infinity).  The optimal ate pairing of ark-ec (Miller loop over
+ * 6x + 2 plus two Frobenius steps on BN254, over |x| on BLS12-381, csrc/pairing.hpp); the line slopes of a G2 point are
+ * computed once and kept, so the fixed h / beta h of a KZG check cost no G2 arithmetic per call; one shared squaring chain
+ * and one final exponentiation for the whole product.  ~0.5 ms for the two pairings of one KZG check on BN254.  Points
+ * off the curve / twist, G1 points outside the prime-order subgroup (BLS12-381) -> ZKT_ERR_INVALID_ARGUMENT; G2
  * subgroup membership is the caller's business (h and beta h come from the trusted VerifierKey). */
 int zkt_pairing_product_is_one(int curve_id, const uint64_t* g1_xy_mont, const uint64_t* g2_xy_mont, size_t n, int* is_one);
-/* The whole of Proof::verify (proof_system/proof.rs:285-503): zkt_verify_prepare, then e(L, h) e(-W, beta h) == 1 for both
- * openings.  h, beta_h: SonicKZG10 VerifierKey::h and ::beta_h (G2).  *accepted = 1 / 0 (Error::ProofVerificationError). */
+/* The whole of Proof::verify (proof_system/proof.rs:285-503): zkt_verify_prepare, then both openings' checks
+ * e(L_k, h) e(-W_k, beta h) == 1 (proof.rs:441,479) folded into one product of two pairings with a 128-bit challenge rho
+ * hashed from (L1, W1, L2, W2, h, beta h): e(L1 + rho L2, h) e(-(W1 + rho W2), beta h) == 1 -- ark-poly-commit's batch_check
+ * folding; a proof failing either check passes with probability 2^-128.  h, beta_h: SonicKZG10 VerifierKey::h and
+ * ::beta_h (G2).  *accepted = 1 / 0 (Error::ProofVerificationError).  ~2.3 ms per BN254 proof on one host core. */
 int zkt_verify(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, const uint64_t* h_g2_mont,
                const uint64_t* beta_h_g2_mont, int* accepted);
 
@@ -362,6 +371,9 @@ int zkt_g1_sum_host(int curve_id, const uint64_t* points_xy_mont, size_t count, 
 /* Elementwise Fr product on the device (out[i] = a[i]*b[i], Montgomery); test hook for the field
  * kernels. Host pointers. */
 int zkt_debug_fr_mul(zkt_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* Self-check of the host pairing's shortcuts against their plain definitions (Frobenius maps = powers by p, sparse
+ * and cyclotomic products = dense ones, the final exponentiation leaves an element of order r).  0 = all good. */
+int zkt_debug_pairing_selftest(int curve_id);
 /* The fused quotient pass alone (quotient_poly.rs:98-224), for per-kernel tests: t(x) on the 4n coset from the loaded
  * circuit's ExtendedProverKey and caller-supplied witness cosets.  challenges: alpha beta gamma delta epsilon (5 x 4
  * words); wit: nine HOST vectors of 4n elements in the order a b c pi z1 z2 t h1 h2 (quotient_poly.rs:52-96).  With

@@ -1,6 +1,7 @@
-"""f4, the last step: the host pairing check (csrc/pairing.hpp, reduced Tate pairing) and the complete
-verifier zkt_verify against the oracle (oracle/pairing.py: the same pairing on Python integers) and against what a
-pairing must do whatever its definition: bilinearity, non-degeneracy, agreement with the trapdoor identity on real
+"""f4, the last step: the host pairing check (csrc/pairing.hpp, optimal ate pairing with prepared G2
+lines) and the complete verifier zkt_verify against the oracle (oracle/pairing.py: the reduced Tate pairing on Python
+integers -- a different pairing, so only "is the product one" is compared, which is all a verifier asks) and against what
+a pairing must do whatever its definition: bilinearity, non-degeneracy, agreement with the trapdoor identity on real
 openings.  "Parity unpinned" by the reference (pairings live in ark-ec, no vector in the tree)."""
 import numpy as np
 import pytest
@@ -108,3 +109,21 @@ def test_pairing_smoke(cv):
     g1 = K.points_to_mont(cv, [C.scalar_mul(cv, a, G), C.neg(cv, G)])
     assert _lib.pairing_product_is_one(cv.name, g1, g2_mont(cv, [H, T.g2_mul(a, H)]))
     assert not _lib.pairing_product_is_one(cv.name, g1, g2_mont(cv, [H, T.g2_mul(a + 1, H)]))
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_g2_half_of_the_test_srs(cv):
+    """zkt_srs_generate_g2: h = the published G2 generator, beta_h = tau h (against the oracle's G2 arithmetic), and the
+    KZG identity e(tau G, h) == e(G, tau h) through the product's own pairing."""
+    T = PR.Tower(cv)
+    H = PR.G2_GENERATORS[cv.name]
+    for tau in (1, 2, 0xBEEFCAFE, cv.fr.p - 1):
+        h, bh = _lib.srs_generate_g2(cv.name, tau)
+        assert np.array_equal(h, g2_mont(cv, [H])[0])
+        assert np.array_equal(bh, g2_mont(cv, [T.g2_mul(tau, H)])[0])
+    tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
+    h, bh = _lib.srs_generate_g2(cv.name, tau)
+    G = C.generator(cv)
+    g1 = K.points_to_mont(cv, [C.scalar_mul(cv, tau, G), C.neg(cv, G)])
+    assert _lib.pairing_product_is_one(cv.name, g1, np.stack([h, bh]))
+    assert not _lib.pairing_product_is_one(cv.name, g1, np.stack([bh, h]))

@@ -99,3 +99,77 @@ def test_multi_scalar_mul_on_arbitrary_points_matches_the_oracle(cv):
     assert inf2 == inf and np.array_equal(got2, got)
     L = cv.fq.limbs64
     assert _lib.g1_msm_host(cv.name, np.zeros((0, 2 * L), np.uint64), np.zeros((0, 4), np.uint64))[1]
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
+def test_host_pairing_shortcuts_agree_with_their_definitions(cv):
+    """csrc/pairing.hpp selftest: Frobenius maps = powers by p, sparse / complex / cyclotomic products = the dense ones,
+    exponentiation by x on cyclotomic squarings = plain square-and-multiply, the final exponentiation leaves order r."""
+    assert z.lib().zkt_debug_pairing_selftest(0 if cv.name == "bn254" else 1) == 0
+
+
+def _point_outside_g1(cv):
+    """A point of E(Fq) of order dividing the cofactor (BLS12-381: h = (x - 1)^2 / 3 > 1): [r] of a random curve point."""
+    p = cv.fq.p
+    x = 5
+    while True:
+        y = C.sqrt_mod((x ** 3 + cv.b) % p, p)
+        if y is not None:
+            small = C.add(cv, C.scalar_mul(cv, cv.fr.p - 1, (x, y)), (x, y))    # [r] P (scalar_mul reduces modulo r)
+            if small is not None:
+                return small
+        x += 1
+
+
+def test_checked_deserialisation_rejects_points_outside_the_prime_order_subgroup():
+    """proof.rs:308: "subgroup checks are done when the proof is deserialised" (ark-serialize's checked path).  BLS12-381
+    has cofactor > 1: a commitment shifted by a point of cofactor order is on the curve and must be refused; so is such
+    a point handed to the pairing check.  (BN254 has cofactor one: every curve point is in G1.)"""
+    cv = F.BLS12_381
+    cs, tau, srs, vk, proof = _proof(cv, "merlin", seed=11)
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    raw = proof.serialize(cv)
+    _prepare(cv, "merlin", vk, srs, pis, raw)                                   # the honest proof passes
+    small = _point_outside_g1(cv)
+    assert C.is_on_curve(cv, small) and C.add(cv, C.scalar_mul(cv, cv.fr.p - 1, small), small) is not None
+    nb = 48
+    for k in (0, 6, 11):                                                        # a_commit, z1_commit, the first opening
+        off = k * nb + (1 if k > 11 else 0)
+        honest = C.point_deserialize_compressed(cv, raw[off:off + nb])
+        shifted = C.add(cv, honest, small)
+        assert C.is_on_curve(cv, shifted)
+        bad = raw[:off] + C.point_serialize_compressed(cv, shifted) + raw[off + nb:]
+        with pytest.raises(z.ZktError):
+            _prepare(cv, "merlin", vk, srs, pis, bad)
+    # the small-order point itself, and the pairing entry point
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, C.point_serialize_compressed(cv, small) + raw[nb:])
+    from oracle import pairing as PR
+    from test_pairing_host import g2_mont
+    H = PR.G2_GENERATORS[cv.name]
+    with pytest.raises(_lib.ZktError):
+        _lib.pairing_product_is_one(cv.name, K.points_to_mont(cv, [small]), g2_mont(cv, [H]))
+    # every multiple of the generator passes the endomorphism test (it is the subgroup check, not a filter on x)
+    G = C.generator(cv)
+    for k in (1, 2, 3, 0xd201000000010000, cv.fr.p - 1):
+        assert _lib.pairing_product_is_one(cv.name, K.points_to_mont(cv, [C.scalar_mul(cv, k, G), None]), g2_mont(cv, [None, H]))
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
+def test_malformed_flag_bytes_are_refused(cv):
+    """ark-serialize SWFlags::from_u8: both flag bits at once is no encoding; one way only to write the point at infinity."""
+    cs, tau, srs, vk, proof = _proof(cv, "merlin", seed=13)
+    pis = [cs.pi[k] for k in sorted(cs.pi)]
+    raw = bytearray(proof.serialize(cv))
+    nb = cv.fq.limbs64 * 8
+    both = bytearray(raw)
+    both[nb - 1] |= 0xC0
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, bytes(both))
+    inf_with_x = bytearray(raw)
+    inf_with_x[nb - 1] = (inf_with_x[nb - 1] & 0x3F) | 0x40                    # infinity flag over a non-zero x
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, bytes(inf_with_x))
+    clean_inf = bytearray(raw)
+    clean_inf[:nb] = bytes(nb - 1) + b"\x40"                                    # the one encoding of the identity parses
+    _prepare(cv, "merlin", vk, srs, pis, bytes(clean_inf))

@@ -341,6 +341,23 @@ def g1_sum_host(curve, points) -> tuple:
     return out, bool(inf.value)
 
 
+def srs_generate_g2(curve, tau: int):
+    """The G2 half of the test SRS (zkt_srs_generate_g2): -> (h, beta_h = tau h), each (4 * fq_limbs,) Montgomery limbs in
+    arkworks' Fp2 layout -- SonicKZG10 VerifierKey::h / ::beta_h for zkt_verify."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    t = np.array([(int(tau) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    h = np.zeros(2 * words, dtype=np.uint64)
+    bh = np.zeros(2 * words, dtype=np.uint64)
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_srs_generate_g2.argtypes = [ctypes.c_int, P64, P64, P64]
+    rc = L.zkt_srs_generate_g2(cid, u64p(t), u64p(h), u64p(bh))
+    if rc:
+        raise ZktError(rc, "zkt_srs_generate_g2")
+    return h, bh
+
+
 def g1_msm_host(curve, points, scalars, montgomery: bool = True) -> tuple:
     """HomomorphicCommitment::multi_scalar_mul (commitment.rs:32-45) on arbitrary points, on the host ->
     (xy limbs, is_infinity)."""
