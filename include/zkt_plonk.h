@@ -287,6 +287,17 @@ typedef struct {
 } zkt_poseidon_params;
 int zkt_poseidon_hash_batch(zkt_ctx* ctx, const zkt_poseidon_params* params, const uint64_t* inputs, size_t batch, int arity,
                             uint64_t* out_hashes, uint64_t* out_states);
+/* The same with everything resident in HBM: zkt_poseidon_load uploads the parameters once (as the kernel's own 29-bit
+ * limbs), zkt_poseidon_hash_batch_dev takes DEVICE pointers, allocates nothing and enqueues on the context's stream
+ * without synchronising.  d_out_states (optional, batch x (rounds + 1) x width scalars, arkworks Montgomery form) is laid
+ * out as a variable map: it can be handed straight to zkt_prove_inputs.variables with wires_on_device = 1, w_l / w_r /
+ * w_o indexing into it, so a Poseidon-heavy witness never crosses PCIe.  half_full_rounds >= 1 and partial_rounds >= 1
+ * (output_hash, spec.rs:267-316, always runs one of each before its loops). */
+typedef struct zkt_poseidon zkt_poseidon;
+int zkt_poseidon_load(zkt_ctx* ctx, const zkt_poseidon_params* params, zkt_poseidon** out);
+void zkt_poseidon_free(zkt_ctx* ctx, zkt_poseidon* params);
+int zkt_poseidon_hash_batch_dev(zkt_ctx* ctx, const zkt_poseidon* params, const void* d_inputs, size_t batch, int arity,
+                                void* d_out_hashes, void* d_out_states);
 
 /* ---- Verifier (proof_system/proof.rs:285-503): zkt_verify_prepare = everything but the pairings,
  * ---- zkt_pairing_product_is_one = the pairings, zkt_verify = both ------------------------------------------------

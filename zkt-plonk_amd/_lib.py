@@ -559,6 +559,37 @@ class Context:
                                              arity, u64p(out), u64p(st.reshape(-1, 4)) if trace else None))
         return (out, st) if trace else out
 
+    def poseidon_load(self, width, half_full, partial, round_constants, mds, domain_tag) -> int:
+        """zkt_poseidon_load: PoseidonConstants resident in HBM -> opaque handle (free with poseidon_free)."""
+        class Params(ctypes.Structure):
+            _fields_ = [("width", ctypes.c_int), ("half_full_rounds", ctypes.c_int), ("partial_rounds", ctypes.c_int),
+                        ("round_constants", ctypes.POINTER(ctypes.c_uint64)), ("mds", ctypes.POINTER(ctypes.c_uint64)),
+                        ("domain_tag", ctypes.POINTER(ctypes.c_uint64))]
+        rc = np.ascontiguousarray(round_constants, dtype=np.uint64).reshape(-1, 4)
+        m = np.ascontiguousarray(mds, dtype=np.uint64).reshape(width * width, 4)
+        tag = np.ascontiguousarray(domain_tag, dtype=np.uint64).reshape(4)
+        assert rc.shape[0] == (2 * half_full + partial) * width
+        prm = Params(width, half_full, partial, u64p(rc), u64p(m), u64p(tag))
+        L = self._L
+        L.zkt_poseidon_load.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.POINTER(ctypes.c_void_p)]
+        h = ctypes.c_void_p()
+        self.check(L.zkt_poseidon_load(self._h, ctypes.byref(prm), ctypes.byref(h)))
+        return h.value
+
+    def poseidon_free(self, handle: int):
+        L = self._L
+        L.zkt_poseidon_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.zkt_poseidon_free.restype = None
+        L.zkt_poseidon_free(self._h, ctypes.c_void_p(handle))
+
+    def poseidon_hash_batch_dev(self, handle: int, d_inputs: int, batch: int, arity: int, d_hashes: int, d_states: int = 0):
+        """zkt_poseidon_hash_batch_dev: device pointers in and out, enqueue only (no allocation, no synchronisation)."""
+        L = self._L
+        vp = ctypes.c_void_p
+        L.zkt_poseidon_hash_batch_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, ctypes.c_int, vp, vp]
+        self.check(L.zkt_poseidon_hash_batch_dev(self._h, vp(handle), vp(d_inputs), batch, arity, vp(d_hashes),
+                                                 vp(d_states) if d_states else None))
+
     # -- device memory ------------------------------------------------------------------------
     def alloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()
@@ -701,6 +732,16 @@ class Context:
         return self._prepare((null, null, null), idx[0].shape[0], table, pi_pos, pi_vals, blinders, False,
                              variables=(u64p(variables) if variables.size else null, variables.shape[0]),
                              idx=[u32p(x) for x in idx], keep=(variables, idx))
+
+    def prepare_vars_dev(self, d_variables: int, n_vars: int, d_w_l: int, d_w_r: int, d_w_o: int, n_rows: int, table, pi_pos,
+                         pi_vals, blinders) -> "PreparedInputs":
+        """The composer's witness layout with everything resident in HBM (wires_on_device = 1): `d_variables` may be a
+        buffer a device kernel filled, e.g. the states of zkt_poseidon_hash_batch_dev."""
+        c64 = lambda p: ctypes.cast(ctypes.c_void_p(p), ctypes.POINTER(ctypes.c_uint64))
+        c32 = lambda p: ctypes.cast(ctypes.c_void_p(p), ctypes.POINTER(ctypes.c_uint32))
+        null = ctypes.POINTER(ctypes.c_uint64)()
+        return self._prepare((null, null, null), n_rows, table, pi_pos, pi_vals, blinders, True,
+                             variables=(c64(d_variables), n_vars), idx=[c32(d_w_l), c32(d_w_r), c32(d_w_o)])
 
     def prove_prepared(self, prep: "PreparedInputs", transcript, next_prep: "PreparedInputs" = None) -> bytes:
         """zkt_prove on prepared inputs.  next_prep announces the proof that follows (zkt_prove_set_next): its
