@@ -69,4 +69,35 @@ extern "C" {
     pub fn zkt_prove_with(ctx: *mut ZktCtx, inputs: *const ZktProveInputs, transcript: *const ZktTranscriptVtable,
                           proof_out: *mut u8, proof_cap: usize, proof_len: *mut usize) -> c_int;
     pub fn zkt_prove_set_next(ctx: *mut ZktCtx, next: *const ZktProveInputs) -> c_int;
+    pub fn zkt_g1_msm_host(curve_id: c_int, points_xy_mont: *const u64, scalars: *const u64, n: usize, scalars_montgomery: c_int,
+                           out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
+    pub fn zkt_verify(curve_id: c_int, inputs: *const ZktVerifyInputs, transcript: *mut c_void, h_g2_mont: *const u64,
+                      beta_h_g2_mont: *const u64, accepted: *mut c_int) -> c_int;
+    pub fn zkt_poseidon_load(ctx: *mut ZktCtx, params: *const ZktPoseidonParams, out: *mut *mut c_void) -> c_int;
+    pub fn zkt_poseidon_free(ctx: *mut ZktCtx, params: *mut c_void);
+    pub fn zkt_poseidon_hash_batch_dev(ctx: *mut ZktCtx, params: *const c_void, d_inputs: *const c_void, batch: usize,
+                                       arity: c_int, d_out_hashes: *mut c_void, d_out_states: *mut c_void) -> c_int;
+}
+
+#[repr(C)]
+pub struct ZktVerifyInputs {
+    pub n: u64,
+    pub vk_commitments: *const u64,
+    pub vk_is_infinity: *const c_int,
+    pub pi_roots: *const u64,
+    pub pub_inputs: *const u64,
+    pub n_pi: usize,
+    pub proof: *const u8,
+    pub proof_len: usize,
+    pub g: *const u64,
+}
+
+#[repr(C)]
+pub struct ZktPoseidonParams {
+    pub width: c_int,
+    pub half_full_rounds: c_int,
+    pub partial_rounds: c_int,
+    pub round_constants: *const u64,
+    pub mds: *const u64,
+    pub domain_tag: *const u64,
 }

@@ -1,6 +1,7 @@
 //! `zkt-plonk-gpu`: the two generic seams of `ZKTPlonk<F, D, PC, T, C, TABLE_SIZE>` (plonk-core/src/plonk.rs:39-52)
-//! bound to the MI355X library.  SOURCE ONLY -- never compiled in the authoring image (no Rust toolchain); the
-//! C-ABI underneath is what the parity tests exercise.  INTEGRATION.md walks through the pieces.
+//! bound to the MI355X library.  SOURCE ONLY: UNCOMPILED AND UNTESTED -- the authoring image has no Rust toolchain and
+//! none of the crates; expect to fix signatures against ark-poly / ark-poly-commit 0.3 when it first meets a compiler.
+//! The C-ABI underneath is what the parity tests exercise.  INTEGRATION.md walks through the pieces.
 pub mod ffi;
 
 use ark_ff::{FftField, PrimeField};
@@ -45,19 +46,23 @@ pub fn check(ctx: *mut ffi::ZktCtx, rc: c_int) -> Result<(), plonk_core::error::
 }
 
 /// `D: EvaluationDomain<F> + EvaluationDomainExt<F>` (prove.rs:70, util.rs:27-59): constants stay arkworks', the four
-/// transforms of util.rs:63-140 run on the GPU.
-#[derive(Copy, Clone, Hash, Eq, PartialEq, Debug)]
+/// transforms of util.rs:63-140 run on the GPU.  Satisfies the bound of `prove` / `ZKTPlonk` as it stands: both traits
+/// are implemented below.
+#[derive(Copy, Clone, Hash, Eq, PartialEq, Debug, ark_serialize::CanonicalSerialize, ark_serialize::CanonicalDeserialize)]
 pub struct GpuDomain<F: FftField> {
     pub inner: Radix2EvaluationDomain<F>,
 }
 
 impl<F: FftField + PrimeField> GpuDomain<F> {
-    pub fn new(n: usize) -> Option<Self> {
-        Radix2EvaluationDomain::new(n).map(|inner| Self { inner })
+    /// `DomainCoeff<F>` also admits group elements, whose layout the library does not speak: only a vector of the scalar
+    /// field itself (4 limbs per element, arkworks' Montgomery form) goes to the device, anything else stays on ark-poly.
+    fn is_scalar_vec<T>() -> bool {
+        core::mem::size_of::<T>() == core::mem::size_of::<F>() && core::any::type_name::<T>() == core::any::type_name::<F>()
     }
 
     /// inverse / coset as in include/zkt_plonk.h zkt_ntt; ark-poly resizes to n, the library zero-pads
-    pub fn run<T: DomainCoeff<F>>(&self, v: &mut Vec<T>, inverse: c_int, coset: c_int) {
+    fn run<T: DomainCoeff<F>>(&self, v: &mut Vec<T>, inverse: c_int, coset: c_int) {
+        debug_assert!(Self::is_scalar_vec::<T>());
         let n = self.inner.size();
         let in_len = v.len();
         v.resize(n, T::zero());
@@ -67,12 +72,36 @@ impl<F: FftField + PrimeField> GpuDomain<F> {
             check(ctx, rc).expect("zkt_ntt");
         });
     }
-    pub fn fft_in_place<T: DomainCoeff<F>>(&self, c: &mut Vec<T>) { self.run(c, 0, 0) }         // util.rs:104-113
-    pub fn ifft_in_place<T: DomainCoeff<F>>(&self, e: &mut Vec<T>) { self.run(e, 1, 0) }        // util.rs:63-86
-    pub fn coset_fft_in_place<T: DomainCoeff<F>>(&self, c: &mut Vec<T>) { self.run(c, 0, 1) }   // util.rs:117-140
-    pub fn coset_ifft_in_place<T: DomainCoeff<F>>(&self, e: &mut Vec<T>) { self.run(e, 1, 1) }  // util.rs:90-100
-    pub fn log_size_of_group(&self) -> u32 { self.inner.log_size_of_group }                     // util.rs:52-58
-    pub fn group_gen(&self) -> F { self.inner.group_gen }
+}
+
+impl<F: FftField + PrimeField> EvaluationDomain<F> for GpuDomain<F> {
+    type Elements = <Radix2EvaluationDomain<F> as EvaluationDomain<F>>::Elements;
+
+    fn new(num_coeffs: usize) -> Option<Self> { Radix2EvaluationDomain::new(num_coeffs).map(|inner| Self { inner }) }
+    fn compute_size_of_domain(num_coeffs: usize) -> Option<usize> { Radix2EvaluationDomain::<F>::compute_size_of_domain(num_coeffs) }
+    fn size(&self) -> usize { self.inner.size() }
+    fn fft_in_place<T: DomainCoeff<F>>(&self, c: &mut Vec<T>) {                                   // util.rs:104-113
+        if Self::is_scalar_vec::<T>() { self.run(c, 0, 0) } else { self.inner.fft_in_place(c) }
+    }
+    fn ifft_in_place<T: DomainCoeff<F>>(&self, e: &mut Vec<T>) {                                  // util.rs:63-86
+        if Self::is_scalar_vec::<T>() { self.run(e, 1, 0) } else { self.inner.ifft_in_place(e) }
+    }
+    fn coset_fft_in_place<T: DomainCoeff<F>>(&self, c: &mut Vec<T>) {                             // util.rs:117-140
+        if Self::is_scalar_vec::<T>() { self.run(c, 0, 1) } else { self.inner.coset_fft_in_place(c) }
+    }
+    fn coset_ifft_in_place<T: DomainCoeff<F>>(&self, e: &mut Vec<T>) {                            // util.rs:90-100
+        if Self::is_scalar_vec::<T>() { self.run(e, 1, 1) } else { self.inner.coset_ifft_in_place(e) }
+    }
+    fn evaluate_all_lagrange_coefficients(&self, tau: F) -> Vec<F> { self.inner.evaluate_all_lagrange_coefficients(tau) }
+    fn vanishing_polynomial(&self) -> ark_poly::univariate::SparsePolynomial<F> { self.inner.vanishing_polynomial() }
+    fn evaluate_vanishing_polynomial(&self, tau: F) -> F { self.inner.evaluate_vanishing_polynomial(tau) }
+    fn element(&self, i: usize) -> F { self.inner.element(i) }
+    fn elements(&self) -> Self::Elements { self.inner.elements() }
+}
+
+impl<F: FftField + PrimeField> plonk_core::util::EvaluationDomainExt<F> for GpuDomain<F> {      // util.rs:27-59
+    fn log_size_of_group(&self) -> u32 { self.inner.log_size_of_group }
+    fn group_gen(&self) -> F { self.inner.group_gen }
 }
 
 /// Repacks `GroupAffine { x, y, infinity }` (repr(Rust)) into x limbs || y limbs, (0, 0) for the identity.
@@ -87,7 +116,5 @@ pub fn pack_g1<G: ark_ec::AffineCurve>(pts: &[G], limbs: usize, xy: impl Fn(&G) 
     out
 }
 
-/// The callback table of `zkt_prove_with` over any `T: TranscriptProtocol<F, PC::Commitment>` and the call that
-/// replaces the body of `proof_system::prove` are spelled out in INTEGRATION.md section 3; they need plonk-core's
-/// crate-private `ProvingComposer`, so they live inside plonk-core under `cfg(feature = "gpu")` rather than here.
-pub mod prover {}
+pub mod kzg;
+pub mod prover;

@@ -19,4 +19,5 @@ from ._lib import (  # noqa: F401
 from .domain import GpuDomain  # noqa: F401
 from .prover import GpuProver, GpuKZG10, seed_transcript, PK_ORDER, NUM_BLINDERS  # noqa: F401
 
-__all__ = ["Context", "ZktError", "GpuDomain", "lib", "lib_path", "CURVE_BN254", "CURVE_BLS12_381"]
+__all__ = ["Context", "ZktError", "Transcript", "GpuDomain", "GpuProver", "GpuKZG10", "seed_transcript", "PK_ORDER",
+           "NUM_BLINDERS", "lib", "lib_path", "CURVE_BN254", "CURVE_BLS12_381", "curve_id", "declared_symbols"]

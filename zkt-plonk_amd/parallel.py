@@ -1,8 +1,14 @@
-"""Multi-GPU layer: one process per GPU.  Independent proofs are sharded across ranks ("the
-MSMs of one proof / of concurrent proofs are independent units"): no data-path collective, torch.distributed (RCCL on
-GPUs, gloo in the CPU tests) only carries the barrier and the max-over-ranks timing that bench.py reports.
-`sharded_msm_combine` is the one exchange step of an MSM whose points are split by index range: an all-gather of the
-partial sums as raw bytes and a local addition (a collective cannot reduce curve points)."""
+"""Multi-GPU layer: one process per GPU, two ways to use the GPUs of a node.
+(a) Independent proofs sharded across ranks (`shard_range`, `gather_proofs`): no data-path collective at all;
+    torch.distributed (RCCL on GPUs, gloo in the CPU tests) only carries the barrier and the max-over-ranks timing that
+    bench.py reports.
+(b) ONE proof across the ranks (`TorchComm`, `LocalGroup`: the communicator behind zkt_ctx_set_comm): index-range MSMs
+    whose partial sums are all-gathered as raw bytes (a collective cannot reduce curve points) and ONE all-gather of the
+    quotient evaluations (4n x 32 B in total) per proof.  The device branch of TorchComm (in-place
+    all_gather_into_tensor on the library's HBM buffer over RCCL) has run with a world of one only: the pool gives
+    one GPU per box, so the multi-GPU device transport is UNVERIFIED ON HARDWARE; bench.py fails (exit 4) if its
+    bytes ever differ from the single-GPU proof's.
+`sharded_msm_combine` is the one exchange step of an MSM whose points are split by index range."""
 from __future__ import annotations
 
 import ctypes
