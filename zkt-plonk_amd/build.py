@@ -55,7 +55,9 @@ def build(force: bool = False, extra_flags=None, jobs: int = 4) -> str:
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         res = list(ex.map(lambda s: _compile(s, hdr_m, force, extra), srcs))
     objs = [o for o, _ in res]
-    if force or any(ch for _, ch in res) or not os.path.exists(LIB):
+    # relink whenever an object is newer than the library (an object compiled by hand counts too)
+    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if force or stale or any(ch for _, ch in res):
         cmd = ["hipcc", "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -16,12 +16,17 @@
 //    wave/block tree reductions for the segment weights and a final doubling step.
 //  * The single resulting point is normalised (one inversion) on the host, which needs the affine
 //    coordinates for the Fiat-Shamir transcript anyway.
+//  * The prover's scalars are polynomial coefficients in arkworks' Montgomery form a = s R mod r.  The table holds
+//    R^-1 P_i instead of P_i (scaled once at load), so sum a_i (R^-1 P_i) = sum s_i P_i and the digits are cut straight
+//    from the words in memory: the into_repr() conversion (a Montgomery product per scalar in each of the two level-1
+//    passes) is gone; canonical scalars (commitment.rs:36-42) are the ones that pay it now.
 #include "ctx.hpp"
 #include "ec.hpp"
 #include "ecx.hpp"
 #include "hostec.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace zkt {
@@ -43,7 +48,7 @@ struct MsmWindows {
 };
 
 constexpr int MSM_HEAVY = 32;       // buckets with more pieces than this are folded by a whole block
-constexpr int MSM_HEAVY_BLOCKS = 512;
+constexpr int MSM_HEAVY_BLOCKS = 64;     // grid-stride over the (normally empty) list of crowded buckets
 
 struct MsmState {
     size_t count = 0;      // bases loaded
@@ -60,9 +65,13 @@ struct MsmState {
     uint32_t* bin_offs = nullptr;                  // [nb1][blocks] level-1 counts, scanned per 4096-tile
     uint32_t* bin_aux = nullptr;                   // tile totals, scanned; last = number of pairs
     uint32_t *bin_start = nullptr, *tile_start = nullptr;   // nb1 + 1 each: level-2 work list
+    void* tile_desc = nullptr;                     // uint2[l2_items]: pair range of every level-2 tile
     uint32_t *cnt2 = nullptr, *pos2 = nullptr;     // [level-2 tiles][256]
     uint32_t* chunk_bucket = nullptr;              // bucket of the first pair of every accumulation chunk
     uint32_t nb1 = 0;                              // level-1 bins
+    uint32_t lb = 8;                               // level-2 key bits: bucket = (bin << lb) | low
+    bool packed = false;                           // (low key, table index, sign) fit ONE 32-bit word: 4-byte pairs
+    int dig = 0;                                   // compile-time window layout of the level-1 kernels (0: generic)
     uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
     uint32_t l2_items = 0;                         // upper bound of level-2 tiles
     // per slot, because the bucket fold that reads them runs on the side stream while the next MSM is already grouping
@@ -76,7 +85,7 @@ struct MsmState {
     void* segT[SLOTS] = {};
     void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
     void* host_result_dev[SLOTS] = {};  // the same memory as the kernels address it
-    size_t acc_threads = 196608;   // resident threads of k_msm_accumulate (occupancy query at setup)
+    size_t acc_threads = 196608;   // chunks an MSM is cut into: resident threads of k_msm_accumulate (occupancy query) x 2
     hipStream_t side = nullptr;
     hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
     bool pending[SLOTS] = {};
@@ -101,7 +110,8 @@ __global__ void k_srs_generate(Affine<typename C::Fq>* out, size_t count, Fe<typ
     using R = typename C::Fr;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    Fe<R> s = fe_from_mont<R>(fe_pow_u64<R>(tau_mont, (uint64_t)(first + i)));
+    // tau^i R^-1 as an integer: the table holds R^-1 P_i (see the header)
+    Fe<R> s = fe_from_mont<R>(fe_from_mont<R>(fe_pow_u64<R>(tau_mont, (uint64_t)(first + i))));
     Xyzz<Q> acc = xyzz_identity<Q>();
     bool started = false;
 #pragma unroll 1
@@ -112,6 +122,40 @@ __global__ void k_srs_generate(Affine<typename C::Fq>* out, size_t count, Fe<typ
             if (started) acc = xyzz_double<Q>(acc);
             if ((e >> b) & 1u) {
                 acc = xyzz_add_mixed<Q>(acc, g);
+                started = true;
+            }
+        }
+    }
+    aff_store<Q>(out + i, xyzz_to_affine<Q>(acc));
+}
+
+// out[i] = [k] in[i] for one fixed scalar k (canonical words): k = R^-1 mod r when a caller's powers become the table's
+// bases, k = R mod r on the way back out (zkt_srs_download).  FROM_FX: `in` is in the table's R' form.
+template <class C, bool FROM_FX>
+__global__ void k_srs_scale(const Affine<typename C::Fq>* in, Affine<typename C::Fq>* out, size_t count, Fe<typename C::Fr> k) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Affine<Q> base = aff_load<Q>(in + i);
+    if (aff_is_inf<Q>(base)) {
+        aff_store<Q>(out + i, base);
+        return;
+    }
+    if (FROM_FX) {
+        base.x = fx_to_ark<Q>(fx_unpack<Q>(base.x));
+        base.y = fx_to_ark<Q>(fx_unpack<Q>(base.y));
+    }
+    Xyzz<Q> acc = xyzz_identity<Q>();
+    bool started = false;
+#pragma unroll 1
+    for (int li = R::N - 1; li >= 0; --li) {
+        uint32_t e = k.v[li];
+#pragma unroll 1
+        for (int b = 31; b >= 0; --b) {
+            if (started) acc = xyzz_double<Q>(acc);
+            if ((e >> b) & 1u) {
+                acc = xyzz_add_mixed<Q>(acc, base);
                 started = true;
             }
         }
@@ -183,6 +227,52 @@ ZKT_D void msm_for_each_digit(const Fe<R>& s, const MsmWindows& win, F&& emit) {
     }
 }
 
+// The same digits with the window layout known at compile time (W windows of LO bits, the first REM one bit wider):
+// every shift, mask and word index folds to a constant and the scalar loads / branches of the generic loop disappear
+// (the level-1 kernels spent as many scalar as vector instructions there).  DIG selects the layout: the two the
+// prover's sizes produce (n = 2^19 .. 2^22 on either curve) have their own instance, everything else runs generic.
+template <int DIG> struct DigitLayout { static constexpr int LO = 0, REM = 0, W = 0; };
+template <> struct DigitLayout<1> { static constexpr int LO = 17, REM = 0, W = 15; };   // 255 bits = 15 x 17
+template <> struct DigitLayout<2> { static constexpr int LO = 17, REM = 1, W = 15; };   // 256 bits = 18 + 14 x 17
+static int msm_digit_layout(const MsmWindows& win, int total_bits) {
+    for (int dig = 1; dig <= 2; ++dig) {
+        const int lo = dig == 1 ? DigitLayout<1>::LO : DigitLayout<2>::LO, rem = dig == 1 ? DigitLayout<1>::REM : DigitLayout<2>::REM,
+                  W = dig == 1 ? DigitLayout<1>::W : DigitLayout<2>::W;
+        if (win.W != W || W * lo + rem != total_bits) continue;
+        bool ok = true;
+        for (int w = 0; w < W; ++w) ok = ok && win.width[w] == lo + (w < rem ? 1 : 0);
+        if (ok) return dig;
+    }
+    return 0;
+}
+template <class R, int DIG, class F>
+ZKT_D void msm_for_each_digit_sel(const Fe<R>& s, const MsmWindows& win, F&& emit) {
+    if constexpr (DIG == 0) {
+        msm_for_each_digit<R>(s, win, emit);
+    } else {
+        constexpr int LO = DigitLayout<DIG>::LO, REM = DigitLayout<DIG>::REM, W = DigitLayout<DIG>::W;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int start = w * LO + (w < REM ? w : REM), c = LO + (w < REM ? 1 : 0);
+            const int word = start >> 5, sh = start & 31;
+            uint64_t v = (word < R::N) ? s.v[word] : 0u;
+            if (word + 1 < R::N) v |= (uint64_t)s.v[word + 1] << 32;
+            const uint32_t raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);   // bits at and above 32 N are zero
+            const uint32_t half = 1u << (c - 1);
+            uint32_t d = raw + carry, neg = 0;
+            if (d > half) {
+                d = (1u << c) - d;
+                neg = 1u;
+                carry = 1u;
+            } else {
+                carry = 0u;
+            }
+            emit(w, d, neg);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // grouping the (bucket, table index) pairs by bucket: a two-level counting sort made for this key
 // shape (at most 18 key bits, roughly uniform digits) instead of a general radix sort.
@@ -193,8 +283,25 @@ ZKT_D void msm_for_each_digit(const Fe<R>& s, const MsmWindows& win, F&& emit) {
 //            the last one writing only the table indices plus offsets[bucket].
 // Order inside a bucket is arbitrary, which is all the accumulation needs.  Zero digits are dropped.
 // ---------------------------------------------------------------------------------------------
-constexpr int MSM_BIN_LB = 8;             // level-2 key bits
-constexpr int MSM_L1_CAP = 15360;         // pairs staged per level-1 workgroup (120 KB of LDS)
+constexpr int MSM_BIN_LB_MAX = 8;         // level-2 key bits (at most: the level-2 tables have 256 columns)
+constexpr int MSM_L1_CAP = 15360;         // 8-byte pairs staged per level-1 workgroup (120 KB of LDS); twice as many 4-byte ones
+// Pair formats after the level-1 split.  When the table index (< W * count), the sign and `lb` low key bits fit 32 bits
+// the pair is ONE word: low key | index << lb | sign << 31 (n = 2^20: 24 index bits, lb = 7, 513 bins); the level-1
+// scatter then writes, and both level-2 passes read, half the bytes.  Otherwise (larger keys) the pair is (key, value).
+struct PairPacked {
+    typedef uint32_t type;
+    static __device__ __forceinline__ type make(uint32_t d, uint32_t idx, uint32_t neg, uint32_t lb) {
+        return (d & ((1u << lb) - 1u)) | (idx << lb) | (neg << 31);
+    }
+    static __device__ __forceinline__ uint32_t low(type v, uint32_t lb) { return v & ((1u << lb) - 1u); }
+    static __device__ __forceinline__ uint32_t val(type v, uint32_t lb) { return ((v & 0x7fffffffu) >> lb) | (v & 0x80000000u); }
+};
+struct PairWide {
+    typedef uint2 type;
+    static __device__ __forceinline__ type make(uint32_t d, uint32_t idx, uint32_t neg, uint32_t) { return make_uint2(d, idx | (neg << 31)); }
+    static __device__ __forceinline__ uint32_t low(type v, uint32_t lb) { return v.x & ((1u << lb) - 1u); }
+    static __device__ __forceinline__ uint32_t val(type v, uint32_t) { return v.y; }
+};
 constexpr int MSM_L2_TILE = 8192;         // pairs per level-2 workgroup
 constexpr int MSM_MAX_NB1 = 1024;         // level-1 bins (one per thread in the scans below)
 
@@ -219,21 +326,52 @@ ZKT_D uint32_t block_excl_scan_1024(uint32_t mine, uint32_t* wsum, uint32_t* tot
     return before + incl - mine;
 }
 
-template <class C>
+// exclusive scan of one value per thread over the FIRST 256 threads of a workgroup (any block size that is a multiple of
+// 64 and at least 256; every thread calls it); `wsum`: 4 LDS words.  Two barriers instead of the sixteen of a stepwise
+// scan: these kernels are chains of latencies, not of arithmetic.
+ZKT_D uint32_t block_excl_scan_256(uint32_t mine, uint32_t* wsum) {
+    const bool in = threadIdx.x < 256;
+    uint32_t incl = in ? mine : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    __syncthreads();   // wsum may still be read from a previous call
+    if (in && (threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6) && w < 4; ++w) before += wsum[w];
+    return before + incl - (in ? mine : 0u);
+}
+
+template <class C, int DIG>
 __global__ __launch_bounds__(1024) void k_msm_bin_count(const Fe<typename C::Fr>* scalars, size_t n, int mont,
-                                                        MsmWindows win, uint32_t per_block, uint32_t nb1,
+                                                        MsmWindows win, uint32_t per_block, uint32_t nb1, uint32_t lb,
                                                         uint32_t* counts) {
     using R = typename C::Fr;
     extern __shared__ uint32_t lds[];
     uint32_t* hist = lds;
     for (uint32_t b = threadIdx.x; b < nb1; b += 1024) hist[b] = 0;
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * per_block + threadIdx.x;
-    if (threadIdx.x < per_block && i < n) {
-        Fe<R> s = fe_load<R>(scalars + i);
-        if (mont) s = fe_from_mont<R>(s);
-        msm_for_each_digit<R>(s, win, [&](int, uint32_t d, uint32_t) {
-            if (d) atomicAdd(&hist[d >> MSM_BIN_LB], 1u);
+    // per_block <= 2048: at most two scalars per thread, both fetched before either is processed (these kernels wait
+    // for memory most of their life, rocprof SQ_WAIT_ANY: every independent load in flight counts)
+    Fe<R> sc[2];
+    bool have[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t k = threadIdx.x + 1024u * t;
+        const size_t i = (size_t)blockIdx.x * per_block + k;
+        have[t] = k < per_block && i < n;
+        if (have[t]) sc[t] = fe_load<R>(scalars + i);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!have[t]) continue;
+        Fe<R> s = sc[t];
+        if (!mont) s = fe_to_mont<R>(s);   // the table holds R^-1 P_i: digits are those of s R
+        msm_for_each_digit_sel<R, DIG>(s, win, [&](int, uint32_t d, uint32_t) {
+            if (d) atomicAdd(&hist[d >> lb], 1u);
         });
     }
     __syncthreads();
@@ -267,7 +405,7 @@ ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, 
 // crowded-bucket counter of this MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
 __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uint32_t* aux, uint32_t nt, uint32_t nblk,
                                                        uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start,
-                                                       uint32_t* heavy_count) {
+                                                       uint2* tile_desc, uint32_t* heavy_count) {
     __shared__ uint32_t wsum[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nt; base += 1024) {
@@ -296,20 +434,32 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uin
         bin_start[threadIdx.x] = s;
         tile_start[threadIdx.x] = ex;   // thread nb1 contributes 0 tiles, so this is the grand total there
     }
+    // [first pair, one past the last pair) of every level-2 tile: the level-2 kernels read ONE descriptor instead of
+    // searching tile_start (ten dependent loads at the head of a workgroup that lives for ten microseconds)
+    if (threadIdx.x < nb1) {
+        const uint32_t be = msm_bin_off(offs, aux, (size_t)(threadIdx.x + 1) * nblk, total);
+        for (uint32_t k = 0; k < tiles; ++k) {
+            const uint32_t ts = s + k * MSM_L2_TILE;
+            tile_desc[ex + k] = make_uint2(ts, (ts + MSM_L2_TILE < be) ? ts + MSM_L2_TILE : be);
+        }
+    }
 }
 
-// LDS: cursor[nb1] | delta[nb1] | stage uint2[MSM_L1_CAP]
-template <class C>
+// LDS: cursor[nb1] | delta[nb1] | first[nb1] | stage PF::type[...]
+// Every workgroup orders its pairs by bin in LDS (positions from LDS atomics on the bin cursors), then one wavefront
+// per bin copies the bin's run to its place in `pairs`: 64 consecutive entries per instruction.
+template <class C, class PF, int DIG>
 __global__ __launch_bounds__(1024) void k_msm_bin_scatter(const Fe<typename C::Fr>* scalars, size_t n, int mont,
                                                           MsmWindows win, uint32_t per_block, size_t count,
-                                                          size_t base_off, uint32_t nb1, const uint32_t* offs,
-                                                          const uint32_t* aux, uint2* pairs) {
+                                                          size_t base_off, uint32_t nb1, uint32_t lb, const uint32_t* offs,
+                                                          const uint32_t* aux, typename PF::type* pairs) {
     using R = typename C::Fr;
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wsum[16];
     uint32_t* cursor = lds;
     uint32_t* delta = lds + nb1;
-    uint2* stage = (uint2*)(lds + 2 * nb1);
+    uint32_t* first = lds + 2 * nb1;
+    typename PF::type* stage = (typename PF::type*)(lds + ((3 * nb1 + 3) & ~3u));
     const size_t total = (size_t)nb1 * gridDim.x;
     // this workgroup's level-1 histogram is the difference of neighbouring scanned counts
     uint32_t g0 = 0, mine = 0;
@@ -322,66 +472,86 @@ __global__ __launch_bounds__(1024) void k_msm_bin_scatter(const Fe<typename C::F
     const uint32_t ex = block_excl_scan_1024(mine, wsum, &staged);
     if (threadIdx.x < nb1) {
         cursor[threadIdx.x] = ex;
+        first[threadIdx.x] = ex;
         delta[threadIdx.x] = g0 - ex;
     }
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * per_block + threadIdx.x;
-    if (threadIdx.x < per_block && i < n) {
-        Fe<R> s = fe_load<R>(scalars + i);
-        if (mont) s = fe_from_mont<R>(s);
-        msm_for_each_digit<R>(s, win, [&](int w, uint32_t d, uint32_t neg) {
+    Fe<R> sc[2];
+    bool have[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {   // per_block <= 2048 (see k_msm_bin_count)
+        const uint32_t k = threadIdx.x + 1024u * t;
+        const size_t i = (size_t)blockIdx.x * per_block + k;
+        have[t] = k < per_block && i < n;
+        if (have[t]) sc[t] = fe_load<R>(scalars + i);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!have[t]) continue;
+        const size_t i = (size_t)blockIdx.x * per_block + threadIdx.x + 1024u * t;
+        Fe<R> s = sc[t];
+        if (!mont) s = fe_to_mont<R>(s);
+        msm_for_each_digit_sel<R, DIG>(s, win, [&](int w, uint32_t d, uint32_t neg) {
             if (d) {
-                const uint32_t at = atomicAdd(&cursor[d >> MSM_BIN_LB], 1u);
-                stage[at] = make_uint2(d, (uint32_t)((size_t)w * count + base_off + i) | (neg << 31));
+                const uint32_t at = atomicAdd(&cursor[d >> lb], 1u);
+                stage[at] = PF::make(d, (uint32_t)((size_t)w * count + base_off + i), neg, lb);
             }
         });
     }
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < staged; j += 1024) {
-        const uint2 kv = stage[j];
-        pairs[delta[kv.x >> MSM_BIN_LB] + j] = kv;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t b = threadIdx.x >> 6; b < nb1; b += 16) {
+        const uint32_t s0 = first[b], e0 = cursor[b], d = delta[b];
+        for (uint32_t j = s0 + lane; j < e0; j += 64) pairs[d + j] = stage[j];
     }
 }
 
 struct L2Item {
-    uint32_t bin, s, e;
+    uint32_t s, e;
     bool valid;
 };
-ZKT_D L2Item msm_l2_item(uint32_t item, uint32_t nb1, const uint32_t* bin_start, const uint32_t* tile_start) {
+ZKT_D L2Item msm_l2_item(uint32_t item, uint32_t nb1, const uint32_t* tile_start, const uint2* tile_desc) {
     L2Item r;
     r.valid = item < tile_start[nb1];
-    r.bin = 0; r.s = 0; r.e = 0;
+    r.s = 0; r.e = 0;
     if (!r.valid) return r;
-    uint32_t lo = 0, hi = nb1 - 1;          // last bin with tile_start[bin] <= item
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (tile_start[mid] <= item) lo = mid; else hi = mid - 1;
-    }
-    r.bin = lo;
-    const uint32_t sub = item - tile_start[lo];
-    r.s = bin_start[lo] + sub * MSM_L2_TILE;
-    const uint32_t be = bin_start[lo + 1];
-    r.e = (r.s + MSM_L2_TILE < be) ? r.s + MSM_L2_TILE : be;
+    const uint2 d = tile_desc[item];
+    r.s = d.x;
+    r.e = d.y;
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_msm_l2_count(const uint2* pairs, uint32_t nb1, const uint32_t* bin_start,
-                                                      const uint32_t* tile_start, uint32_t* cnt2) {
+template <class PF>
+__global__ __launch_bounds__(256) void k_msm_l2_count(const typename PF::type* pairs, uint32_t nb1, uint32_t lb,
+                                                      const uint32_t* tile_start, const uint2* tile_desc, uint32_t* cnt2) {
     __shared__ uint32_t hist[256];
-    const L2Item it = msm_l2_item(blockIdx.x, nb1, bin_start, tile_start);
+    const L2Item it = msm_l2_item(blockIdx.x, nb1, tile_start, tile_desc);
     if (!it.valid) return;
     hist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t p = it.s + threadIdx.x; p < it.e; p += 256) atomicAdd(&hist[pairs[p].x & 255u], 1u);
+    // eight independent loads per thread in flight before the first LDS atomic
+    const uint32_t cnt = it.e - it.s;
+    for (uint32_t base = 0; base < cnt; base += 256u * 8u) {
+        typename PF::type v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t j = base + 256u * k + threadIdx.x;
+            if (j < cnt) v[k] = pairs[it.s + j];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t j = base + 256u * k + threadIdx.x;
+            if (j < cnt) atomicAdd(&hist[PF::low(v[k], lb)], 1u);
+        }
+    }
     __syncthreads();
     cnt2[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
 // one workgroup per bin: positions of every (tile, bucket) run and offsets[bucket]
 __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint32_t* pos2, const uint32_t* bin_start,
-                                                     const uint32_t* tile_start, uint32_t* offsets, uint32_t B,
+                                                     const uint32_t* tile_start, uint32_t* offsets, uint32_t B, uint32_t lb,
                                                      uint32_t chunk, uint32_t* chunk_bucket) {
-    __shared__ uint32_t tot[256];
     const uint32_t b = blockIdx.x;
     const uint32_t t0 = tile_start[b], t1 = tile_start[b + 1];
     uint32_t run = 0;
@@ -390,24 +560,19 @@ __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint3
         pos2[at] = run;
         run += cnt2[at];
     }
-    tot[threadIdx.x] = run;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (uint32_t)d) ? tot[threadIdx.x - d] : 0u;
-        __syncthreads();
-        tot[threadIdx.x] += v;
-        __syncthreads();
-    }
-    const uint32_t first = bin_start[b] + tot[threadIdx.x] - run;
-    const uint32_t key = b * 256u + threadIdx.x;
-    offsets[key] = first;   // sized nb1 * 256 + 2; keys above B are empty and repeat the end
+    __shared__ uint32_t wsum4[4];
+    const uint32_t first = bin_start[b] + block_excl_scan_256(run, wsum4);
+    // bucket = (bin << lb) | low; columns at or above 2^lb of the 256 never receive a pair and own no bucket
+    const bool owns = threadIdx.x < (1u << lb);
+    const uint32_t key = (b << lb) + threadIdx.x;
+    if (owns) offsets[key] = first;   // sized (nb1 << lb) + 2; keys above B are empty and repeat the end
     // accumulation chunk t starts at pair t * chunk: tell it which bucket that pair belongs to.  A bucket normally
     // covers a handful of chunks; a crowded one (skewed digits) is written by the whole workgroup.
     __shared__ uint32_t big[256][3];
     __shared__ uint32_t nbig;
     if (threadIdx.x == 0) nbig = 0;
     __syncthreads();
-    if (key >= 1 && key <= B && run) {
+    if (owns && key >= 1 && key <= B && run) {
         const uint32_t tb = (first + chunk - 1) / chunk;
         const uint32_t te = (uint32_t)(((uint64_t)first + run + chunk - 1) / chunk);   // one past the last chunk start inside
         if (te - tb > 64) {
@@ -423,39 +588,55 @@ __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint3
     for (uint32_t t = t0; t < t1; ++t) pos2[(size_t)t * 256 + threadIdx.x] += first;
 }
 
-__global__ __launch_bounds__(256) void k_msm_l2_scatter(const uint2* pairs, uint32_t nb1, const uint32_t* bin_start,
-                                                        const uint32_t* tile_start, const uint32_t* cnt2,
-                                                        const uint32_t* pos2, uint32_t* vals) {
-    __shared__ uint32_t cursor[256], delta[256];
+// 1024 threads per 8192-pair tile: the 42 KB of LDS allow two such workgroups (32 waves) per CU, where 256-thread
+// workgroups left 12 waves to hide the latency this kernel consists of.  The pair loads are issued before the scan of
+// the 256 counters, so that they travel while it runs.
+constexpr int MSM_L2S_THREADS = 1024;
+constexpr int MSM_L2S_PER = MSM_L2_TILE / MSM_L2S_THREADS;   // pairs per thread
+template <class PF>
+__global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typename PF::type* pairs, uint32_t nb1, uint32_t lb,
+                                                                    const uint32_t* tile_start, const uint2* tile_desc,
+                                                                    const uint32_t* cnt2, const uint32_t* pos2,
+                                                                    uint32_t* vals) {
+    __shared__ uint32_t cursor[256], delta[256], wsum4[4];
     __shared__ uint32_t sval[MSM_L2_TILE];
     __shared__ uint8_t skey[MSM_L2_TILE];
-    const L2Item it = msm_l2_item(blockIdx.x, nb1, bin_start, tile_start);
+    const L2Item it = msm_l2_item(blockIdx.x, nb1, tile_start, tile_desc);
     if (!it.valid) return;
-    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t mine = cnt2[at];
-    cursor[threadIdx.x] = mine;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (uint32_t)d) ? cursor[threadIdx.x - d] : 0u;
-        __syncthreads();
-        cursor[threadIdx.x] += v;
-        __syncthreads();
-    }
-    const uint32_t ex = cursor[threadIdx.x] - mine;
-    __syncthreads();
-    cursor[threadIdx.x] = ex;
-    delta[threadIdx.x] = pos2[at] - ex;
-    __syncthreads();
-    for (uint32_t p = it.s + threadIdx.x; p < it.e; p += 256) {
-        const uint2 kv = pairs[p];
-        const uint32_t low = kv.x & 255u;
-        const uint32_t a = atomicAdd(&cursor[low], 1u);
-        sval[a] = kv.y;
-        skey[a] = (uint8_t)low;
-    }
-    __syncthreads();
     const uint32_t cnt = it.e - it.s;
-    for (uint32_t j = threadIdx.x; j < cnt; j += 256) vals[delta[skey[j]] + j] = sval[j];
+    typename PF::type v[MSM_L2S_PER];
+#pragma unroll
+    for (int k = 0; k < MSM_L2S_PER; ++k) {
+        const uint32_t j = (uint32_t)MSM_L2S_THREADS * k + threadIdx.x;
+        if (j < cnt) v[k] = pairs[it.s + j];
+    }
+    uint32_t mine = 0, p2 = 0;
+    if (threadIdx.x < 256) {
+        mine = cnt2[(size_t)blockIdx.x * 256 + threadIdx.x];
+        p2 = pos2[(size_t)blockIdx.x * 256 + threadIdx.x];
+    }
+    const uint32_t ex = block_excl_scan_256(mine, wsum4);
+    if (threadIdx.x < 256) {
+        cursor[threadIdx.x] = ex;
+        delta[threadIdx.x] = p2 - ex;
+    }
+    __syncthreads();
+    uint32_t a[MSM_L2S_PER];
+#pragma unroll
+    for (int k = 0; k < MSM_L2S_PER; ++k) {
+        const uint32_t j = (uint32_t)MSM_L2S_THREADS * k + threadIdx.x;
+        if (j < cnt) a[k] = atomicAdd(&cursor[PF::low(v[k], lb)], 1u);
+    }
+#pragma unroll
+    for (int k = 0; k < MSM_L2S_PER; ++k) {
+        const uint32_t j = (uint32_t)MSM_L2S_THREADS * k + threadIdx.x;
+        if (j < cnt) {
+            sval[a[k]] = PF::val(v[k], lb);
+            skey[a[k]] = (uint8_t)PF::low(v[k], lb);
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < cnt; j += MSM_L2S_THREADS) vals[delta[skey[j]] + j] = sval[j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -688,6 +869,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         st->W = W;
         st->c = lo + (rem ? 1 : 0);
         cb = st->c;
+        st->dig = msm_digit_layout(st->win, total);
     }
     st->B = 1u << (cb - 1);
     if ((uint64_t)st->W * count >= ((uint64_t)1 << 31))
@@ -697,25 +879,40 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     size_t m = (size_t)st->W * count;
     if ((rc = dev_alloc(c, (void**)&st->vals2, m * 4))) return rc;
     if ((rc = dev_alloc(c, &st->pairs, m * 8))) return rc;
-    st->nb1 = (st->B >> MSM_BIN_LB) + 1;
-    if (st->nb1 > (uint32_t)MSM_MAX_NB1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm: too many level-1 bins");
-    st->l1_scalars = (uint32_t)(MSM_L1_CAP / st->W) & ~63u;
-    if (st->l1_scalars > 1024) st->l1_scalars = 1024;
+    {   // pair format: one 32-bit word when low key bits + table index + sign fit (see PairPacked)
+        int idx_bits = 1;
+        while ((m - 1) >> idx_bits) ++idx_bits;
+        int lb = 31 - idx_bits;
+        if (lb > MSM_BIN_LB_MAX) lb = MSM_BIN_LB_MAX;
+        st->packed = lb >= 4 && ((st->B >> lb) + 1) < (uint32_t)MSM_MAX_NB1;
+        st->lb = st->packed ? (uint32_t)lb : (uint32_t)MSM_BIN_LB_MAX;
+    }
+    st->nb1 = (st->B >> st->lb) + 1;
+    if (st->nb1 >= (uint32_t)MSM_MAX_NB1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm: too many level-1 bins");
+    // staged pairs per level-1 workgroup: MSM_L1_CAP of either format; the 4-byte format then needs 60 KB of LDS and two
+    // workgroups (32 waves) share a CU, which these latency-bound kernels need more than longer runs
+    const uint32_t l1_cap = (uint32_t)MSM_L1_CAP;
+    st->l1_scalars = (l1_cap / (uint32_t)st->W) & ~63u;
+    if (st->l1_scalars > 1024u) st->l1_scalars = 1024u;
     const size_t max_blk = (count + st->l1_scalars - 1) / st->l1_scalars;
     if ((rc = dev_alloc(c, (void**)&st->bin_offs, ((size_t)st->nb1 * max_blk + 1) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->bin_aux, ((size_t)st->nb1 * max_blk / MSM_SCAN_TILE + 4) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->bin_start, ((size_t)st->nb1 + 1) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->tile_start, ((size_t)st->nb1 + 1) * 4))) return rc;
     st->l2_items = (uint32_t)(m / MSM_L2_TILE + st->nb1);
+    if ((rc = dev_alloc(c, &st->tile_desc, (size_t)st->l2_items * 8))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->cnt2, (size_t)st->l2_items * 256 * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->pos2, (size_t)st->l2_items * 256 * 4))) return rc;
     {
-        const int lds = (int)(2 * st->nb1 * 4 + MSM_L1_CAP * 8);
-        ZKT_HIP(c, hipFuncSetAttribute((const void*)k_msm_bin_scatter<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int lds = (int)(((3 * st->nb1 + 3) & ~3u) * 4 + MSM_L1_CAP * (st->packed ? 4 : 8));
+        const void* fns[6] = {(const void*)k_msm_bin_scatter<C, PairPacked, 0>, (const void*)k_msm_bin_scatter<C, PairPacked, 1>,
+                              (const void*)k_msm_bin_scatter<C, PairPacked, 2>, (const void*)k_msm_bin_scatter<C, PairWide, 0>,
+                              (const void*)k_msm_bin_scatter<C, PairWide, 1>,   (const void*)k_msm_bin_scatter<C, PairWide, 2>};
+        for (const void* f : fns) ZKT_HIP(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     static_assert(MsmState::SLOTS == 11, "per-slot arrays are sized for 11 slots");
     for (int i = 0; i < MsmState::SLOTS; ++i) {
-        if ((rc = dev_alloc(c, (void**)&st->offsets[i], ((size_t)st->nb1 * 256 + 2) * 4))) return rc;
+        if ((rc = dev_alloc(c, (void**)&st->offsets[i], (((size_t)st->nb1 << st->lb) + 2) * 4))) return rc;
         if ((rc = dev_alloc(c, (void**)&st->heavy[i], ((size_t)st->B + 2) * 4))) return rc;
     }
     {
@@ -725,6 +922,17 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_msm_accumulate<C>, 256, 0) == hipSuccess &&
             blocks_per_cu > 0 && cus > 0)
             st->acc_threads = (size_t)blocks_per_cu * cus * 256;
+        // Twice as many chunks as the chip keeps resident: the bucket reduction of the previous MSM runs on the side stream
+        // while this accumulation starts, and every one of its workgroups holds the registers of an accumulation
+        // workgroup for 100-200 us.  With exactly one wave-front of chunks the workgroups that could not start on time
+        // ended a whole accumulation late (+8 % on the kernel); with two, the dispatcher gives the delayed CUs fewer of
+        // the second half.  (ZKT_MSM_OVER = 1 .. 8 overrides the factor for experiments.)
+        int over = 2;
+        if (const char* e = getenv("ZKT_MSM_OVER")) {
+            const int f = atoi(e);
+            if (f >= 1 && f <= 8) over = f;
+        }
+        st->acc_threads *= (size_t)over;
     }
     // chunk = max(ceil(pairs / acc_threads), MSM_CHUNK_MIN) pairs per thread, so an MSM never cuts its pairs into more
     // than acc_threads chunks (nor more than pairs / MSM_CHUNK_MIN): that bounds the piece array of every slot
@@ -733,7 +941,14 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
     size_t nseg = st->B / MSM_SEG;
-    ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // numerically lower = higher priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* e = getenv("ZKT_MSM_SIDE_PRIO");
+        if (e && !strcmp(e, "hi")) ZKT_HIP(c, hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, hi));
+        else if (e && !strcmp(e, "lo")) ZKT_HIP(c, hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, lo));
+        else ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+    }
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segA[i], nseg * sizeof(Xyzz<Q>)))) return rc;
@@ -770,7 +985,7 @@ void msm_release(zkt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
     void* ptrs[] = {st.table,     st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
-                    st.tile_start, st.cnt2,   st.pos2,  st.chunk_bucket};
+                    st.tile_start, st.cnt2,   st.pos2,  st.chunk_bucket, st.tile_desc};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]);
@@ -790,6 +1005,15 @@ static int srs_load_t(zkt_ctx* c, const void* src, size_t count, bool src_on_dev
     c->msm->total = total ? total : count;
     ZKT_HIP(c, hipMemcpyAsync(c->msm->table, src, count * sizeof(Affine<Q>),
                               src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    {   // bases R^-1 P_i (see the header): one fixed-scalar multiplication per power, once per key
+        using R = typename C::Fr;
+        Fe<R> raw_one = fe_zero<R>();
+        raw_one.v[0] = 1u;
+        const Fe<R> rinv = fe_from_mont<R>(raw_one);   // R^-1 mod r as an integer
+        hipLaunchKernelGGL((k_srs_scale<C, false>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0, c->stream,
+                           (const Affine<Q>*)c->msm->table, (Affine<Q>*)c->msm->table, count, rinv);
+        ZKT_HIP(c, hipGetLastError());
+    }
     return srs_finish<C>(c);
 }
 
@@ -849,8 +1073,8 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     // the slot's buffers may still be read by the previous MSM that used this slot (side stream)
     if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
     const uint32_t m = (uint32_t)((size_t)st.W * n);
-    // one chunk per thread, and exactly as many threads as the chip keeps resident for this kernel: the
-    // whole array is consumed in a single wave-front with no partially filled last round
+    // one chunk per thread, two wave-fronts of threads (see msm_setup): equal chunks keep the lanes balanced whatever the
+    // digit distribution, the second wave-front absorbs the workgroups the side stream's kernels delayed
     uint32_t chunk = (uint32_t)((m + st.acc_threads - 1) / st.acc_threads);
     if (chunk < (uint32_t)MSM_CHUNK_MIN) chunk = MSM_CHUNK_MIN;
     {
@@ -859,23 +1083,42 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         const uint32_t S = st.l1_scalars;
         const unsigned nblk = (unsigned)((n + S - 1) / S);
         const uint32_t total = st.nb1 * nblk, ntiles = (total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
-        hipLaunchKernelGGL(k_msm_bin_count<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream,
-                           (const Fe<R>*)d_scalars, n, mont, st.win, S, st.nb1, st.bin_offs);
+        {
+            auto kc = st.dig == 1 ? k_msm_bin_count<C, 1> : st.dig == 2 ? k_msm_bin_count<C, 2> : k_msm_bin_count<C, 0>;
+            hipLaunchKernelGGL(kc, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream, (const Fe<R>*)d_scalars, n, mont,
+                               st.win, S, st.nb1, st.lb, st.bin_offs);
+        }
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
         hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
-                           st.bin_start, st.tile_start, st.heavy[slot]);
+                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, st.heavy[slot]);
         ZKT_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_msm_bin_scatter<C>, dim3(nblk), dim3(1024), (size_t)st.nb1 * 8 + (size_t)MSM_L1_CAP * 8,
-                           c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S, st.count, base_off, st.nb1,
-                           st.bin_offs, st.bin_aux, (uint2*)st.pairs);
-        ZKT_HIP(c, hipGetLastError());
+        const size_t lds_scatter = (size_t)((3 * st.nb1 + 3) & ~3u) * 4 + (size_t)MSM_L1_CAP * (st.packed ? 4 : 8);
         const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
-        hipLaunchKernelGGL(k_msm_l2_count, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
-                           st.bin_start, st.tile_start, st.cnt2);
+        if (st.packed) {
+            auto ks = st.dig == 1 ? k_msm_bin_scatter<C, PairPacked, 1> : st.dig == 2 ? k_msm_bin_scatter<C, PairPacked, 2>
+                                                                                          : k_msm_bin_scatter<C, PairPacked, 0>;
+            hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
+                               st.count, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
+            ZKT_HIP(c, hipGetLastError());
+            hipLaunchKernelGGL(k_msm_l2_count<PairPacked>, dim3(items), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
+                               st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
+        } else {
+            auto ks = st.dig == 1 ? k_msm_bin_scatter<C, PairWide, 1> : st.dig == 2 ? k_msm_bin_scatter<C, PairWide, 2>
+                                                                                          : k_msm_bin_scatter<C, PairWide, 0>;
+            hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
+                               st.count, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+            ZKT_HIP(c, hipGetLastError());
+            hipLaunchKernelGGL(k_msm_l2_count<PairWide>, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+                               st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
+        }
         hipLaunchKernelGGL(k_msm_l2_scan, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
-                           st.tile_start, st.offsets[slot], st.B, chunk, st.chunk_bucket);
-        hipLaunchKernelGGL(k_msm_l2_scatter, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
-                           st.bin_start, st.tile_start, st.cnt2, st.pos2, st.vals2);
+                           st.tile_start, st.offsets[slot], st.B, st.lb, chunk, st.chunk_bucket);
+        if (st.packed)
+            hipLaunchKernelGGL(k_msm_l2_scatter<PairPacked>, dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint32_t*)st.pairs,
+                               st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2);
+        else
+            hipLaunchKernelGGL(k_msm_l2_scatter<PairWide>, dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+                               st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2);
         ZKT_HIP(c, hipGetLastError());
     }
     {
@@ -1067,26 +1310,31 @@ int srs_generate(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t slice_of
     if (c->curve == ZKT_CURVE_BN254) return srs_generate_t<Bn254Curve>(c, tau4, count, slice_off, total);
     return srs_generate_t<Bls381Curve>(c, tau4, count, slice_off, total);
 }
-template <class Q>
-static void table_to_ark(Affine<Q>* pts, size_t count) {
-    for (size_t i = 0; i < count; ++i) {
-        if (aff_is_inf<Q>(pts[i])) continue;
-        pts[i].x = fx_to_ark<Q>(fx_unpack<Q>(pts[i].x));
-        pts[i].y = fx_to_ark<Q>(fx_unpack<Q>(pts[i].y));
-    }
+template <class C>
+static int srs_download_t(zkt_ctx* c, size_t offset, size_t count, uint64_t* out) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    // the table holds R^-1 P_i in R' form: hand back the caller's own powers, P_i = [R] (R^-1 P_i), in arkworks' form
+    // (test / bench aid; a fixed-scalar multiplication per point on the device)
+    if (count == 0) return ZKT_OK;
+    void* tmp = nullptr;
+    int rc = dev_alloc(c, &tmp, count * sizeof(Affine<Q>));
+    if (rc) return rc;
+    const Fe<R> r_canon = fe_one<R>();   // the Montgomery form of one = R mod r, read as an integer
+    hipLaunchKernelGGL((k_srs_scale<C, true>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0, c->stream,
+                       (const Affine<Q>*)c->msm->table + offset, (Affine<Q>*)tmp, count, r_canon);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, tmp, count * sizeof(Affine<Q>), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, tmp);
+    return e == hipSuccess ? ZKT_OK : hip_fail(c, e, "srs_download");
 }
 
 int srs_download(zkt_ctx* c, size_t offset, size_t count, uint64_t* out) {
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded");
     if (offset > c->msm->count || count > c->msm->count - offset) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "range");
-    size_t psz = (c->curve == ZKT_CURVE_BN254) ? sizeof(Affine<Bn254Fq>) : sizeof(Affine<Bls381Fq>);
-    ZKT_HIP(c, hipMemcpyAsync(out, (const char*)c->msm->table + offset * psz, count * psz, hipMemcpyDeviceToHost,
-                              c->stream));
-    ZKT_HIP(c, hipStreamSynchronize(c->stream));
-    // the device table is kept in R' = 2^(29 L) Montgomery form; hand back arkworks' R form (test / bench aid)
-    if (c->curve == ZKT_CURVE_BN254) table_to_ark<Bn254Fq>((Affine<Bn254Fq>*)out, count);
-    else table_to_ark<Bls381Fq>((Affine<Bls381Fq>*)out, count);
-    return ZKT_OK;
+    if (c->curve == ZKT_CURVE_BN254) return srs_download_t<Bn254Curve>(c, offset, count, out);
+    return srs_download_t<Bls381Curve>(c, offset, count, out);
 }
 void msm_info(zkt_ctx* c, int* cbits, int* windows, size_t* count) {
     if (!c->msm) {

@@ -152,6 +152,7 @@ struct Prover {
     Prover(zkt_ctx* ctx, CircuitState& st, HostTranscript& t) : c(ctx), S(st), tr(t) {
         trace_on = getenv("ZKT_HOST_TRACE") != nullptr;
     }
+    bool copy_fenced = false;   // the copy stream already waits for the main stream's earlier work (run(), cold path)
     // ZKT_HOST_TRACE=1: wall-clock marks of the host control path (where the GPU may be waiting for the host)
     bool trace_on = false;
     std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
@@ -441,8 +442,11 @@ struct Prover {
         if (host_wires) {
             // cold path: the three wire vectors cross PCIe inside the call.  They travel on the copy stream while the main
             // stream already transforms and commits the wire before, so only the first upload is exposed.
-            ZKT_HIP(c, hipEventRecord(S.ev_copy[3], c->stream));       // the targets are free once earlier work has drained
-            ZKT_HIP(c, hipStreamWaitEvent(S.copy_stream, S.ev_copy[3], 0));
+            if (!copy_fenced) {
+                ZKT_HIP(c, hipEventRecord(S.ev_copy[3], c->stream));   // the targets are free once earlier work has drained
+                ZKT_HIP(c, hipStreamWaitEvent(S.copy_stream, S.ev_copy[3], 0));
+            }
+            copy_fenced = false;
             for (int k = 0; k < 3; ++k) {
                 if (in.n_rows < n)
                     ZKT_HIP(c, hipMemsetAsync((char*)S.ev[k] + in.n_rows * 32, 0, (n - in.n_rows) * 32, S.copy_stream));
@@ -527,6 +531,13 @@ struct Prover {
             // nobody announced this proof: a fresh lookup table's polynomial goes first (it waits for nothing, and its
             // commitment covers the first wire upload of a cold proof)
             const bool table_first = !table_is_cached(in);
+            if (table_first && in.a_evals && !in.wires_on_device) {
+                // host wire vectors: the copy stream is fenced HERE, so that the uploads run beside the table's work
+                // instead of behind it
+                ZKT_HIP(c, hipEventRecord(S.ev_copy[3], c->stream));
+                ZKT_HIP(c, hipStreamWaitEvent(S.copy_stream, S.ev_copy[3], 0));
+                copy_fenced = true;
+            }
             if (table_first && (rc = enqueue_table(in, true))) return rc;
             if ((rc = enqueue_round_1(in))) return rc;
             if ((rc = enqueue_round_2(in, &same_table, table_first))) return rc;
