@@ -813,8 +813,17 @@ __global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::
     }
     const Xyzz<Q>* src = (y == 0) ? segA : segT;
     XyzzX<Q> acc = xx_identity<Q>();
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
-        if (y == 0 || ((s >> (y - 1)) & 1u)) acc = xx_add<Q>(acc, xx_load<Q>(src + s));
+    if (y == 0) {
+        for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
+            acc = xx_add<Q>(acc, xx_load<Q>(src + s));
+    } else {
+        // only the segments whose index has bit k set take part: enumerate THEM (q -> q with a one inserted at bit k),
+        // so that every lane adds on every trip instead of idling through the half that a mask would skip
+        const uint32_t k = (uint32_t)(y - 1), low = (1u << k) - 1u;
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nseg / 2; q += gridDim.x * blockDim.x) {
+            const uint32_t s = ((q & ~low) << 1) | (1u << k) | (q & low);
+            if (s < nseg) acc = xx_add<Q>(acc, xx_load<Q>(src + s));
+        }
     }
     acc = block_sum_256<Q>(acc, wsum);
     if (threadIdx.x == 0) xx_store_ark<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
