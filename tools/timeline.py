@@ -8,7 +8,12 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 anchors = [i for i, r in enumerate(rows) if "k_quotient" in r["Kernel_Name"]]
 if len(anchors) < 3:
     sys.exit("need >= 3 proofs in the trace")
-a0, a1 = anchors[-2], anchors[-1]
+# which pair of consecutive proofs: k-th from the end (bench.py: warm-up, the timed proofs, then a profiling pass with every
+# event scope on -- the timed region is what the timeline should show, so prof_stats.sh passes the index of a timed proof)
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if len(anchors) < k + 1:
+    sys.exit("not enough proofs in the trace")
+a0, a1 = anchors[-k - 1], anchors[-k]
 t0, t1 = int(rows[a0]["Start_Timestamp"]), int(rows[a1]["Start_Timestamp"])
 sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 print("window (quotient to quotient): %.3f ms, %d dispatches" % ((t1 - t0) / 1e6, len(sel)))
