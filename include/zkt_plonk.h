@@ -87,7 +87,10 @@ const char* zkt_version(void);
  * Everything else (the n-point inverse transforms, grand products, evaluations, openings' polynomials, Fiat-Shamir) is
  * replicated: every rank produces the same proof bytes, equal to the single-GPU bytes.
  * The communicator is supplied by the caller (torch.distributed over RCCL in zkt-plonk_amd/parallel.py; any other
- * transport in a Rust host).  all_gather: `bytes` per rank, results in rank order; on_device = 0: host pointers;
+ * transport in a Rust host; the device branch of that Python transport -- an in-place all-gather on the library's own HBM
+ * buffer -- has only ever run with a world of one: no multi-GPU node was available, it is UNVERIFIED ON HARDWARE; the
+ * sharded prover itself is byte-checked with thread and gloo ranks on one GPU up to BLS12-381 n = 2^22 x 8 ranks).
+ * all_gather: `bytes` per rank, results in rank order; on_device = 0: host pointers;
  * on_device = 1 (only if device_buffers != 0): device pointers, the library has synchronised `hip_stream` before the
  * call and the exchange must be complete when the callback returns.  Returns 0 on success. */
 typedef struct {
