@@ -191,3 +191,27 @@ def test_msm_full_size_2_20(cv, ctxs):
     pb = _pt(cv, *ctx.msm(b[:4096]))
     pab = _pt(cv, *ctx.msm(ab))
     assert C.add(cv, pa, pb) == pab
+
+
+def test_msm_2_21_wide_pairs_with_compile_time_digits(ctxs):
+    """BN254 at n = 2^21: the table index no longer fits a 4-byte pair (26 index bits), so the level-1 split writes
+    (key, value) pairs, while the window layout (15 x 17 bits) still takes the compile-time digit path -- the one
+    combination the prover's configs do not reach.  Canonical and Montgomery scalars, against the oracle."""
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    n = 1 << 21
+    ctx.srs_generate(0xA5A5, n)
+    assert ctx.msm_info()["windows"] == 15
+    srs = ctx.srs_download(0, n)
+    assert np.array_equal(srs[:32], K.srs_mont(cv, 0xA5A5, 32))          # the table's R^-1 scaling is undone on the way out
+    rng = np.random.default_rng(21)
+    a = rand_fr(rng, n)
+    a[::1000] = 0
+    out, inf = ctx.msm(a)
+    want, winf = K.msm_mont(cv, srs, a)
+    assert not inf and np.array_equal(out, want)
+    canon = K.ints_to_limbs(K.fr_from_mont(cv, a[:50000]), 4)
+    out2, inf2 = ctx.msm(canon, montgomery=False)
+    want2, _ = K.msm_mont(cv, srs[:50000], a[:50000])
+    assert np.array_equal(out2, want2)
+    ctx.srs_generate(0x5EED, 64)                                            # release the 2 GiB table

@@ -35,7 +35,7 @@ constexpr int MSM_CHUNK_MIN = 16;  // grouped pairs per accumulation thread: at 
                                    // chunk is sized so that ONE resident wave-front of threads covers the array
 constexpr int MSM_LOG_SEG = 2;
 constexpr int MSM_SEG = 1 << MSM_LOG_SEG;   // buckets per running-sum segment
-constexpr int MSM_R2_BLOCKS = 8;
+constexpr int MSM_R2_BLOCKS = 1;     // partial sums per row handed to the host
 constexpr int MSM_MAX_Y = 24;
 
 // Window layout: W windows of width c or c-1 covering exactly lambda+1 bits, so that no window
@@ -83,6 +83,7 @@ struct MsmState {
     void* buckets[SLOTS] = {};      // Xyzz[B + 1]
     void* segA[SLOTS] = {};         // Xyzz[B / SEG]
     void* segT[SLOTS] = {};
+    void* rowcol[SLOTS] = {};       // Xyzz[NI + NJ + MSM_A_PARTS]: row / column sums of segT, partial sums of segA
     void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
     void* host_result_dev[SLOTS] = {};  // the same memory as the kernels address it
     size_t acc_threads = 196608;   // chunks an MSM is cut into: resident threads of k_msm_accumulate (occupancy query) x 2
@@ -795,38 +796,86 @@ __global__ __launch_bounds__(256) void k_msm_segments(const Xyzz<typename C::Fq>
     xx_store<Q>(segT + s, run);
 }
 
-// y = 0: plain sum of segA ; y = k + 1 (< ny): sum of segT[s] over s with bit k set ; y = ny: the top bucket alone.
-// One partial per block, written in arkworks' R form: the host adds them up and applies the weights
-// (hostec.hpp weighted_row_sum) -- the remaining ~35 dependent curve operations cost a wavefront 0.6 ms and the host 15 us.
+// The weighted sum over segments, sum_s s T_s, through row and column sums: with s = i NJ + j (NJ = 2^q2 columns,
+// NI = 2^q1 rows) the sum of T_s over the s whose bit k is set equals the sum of the COLUMN sums C_j over the j with bit k
+// (k < q2), or of the ROW sums R_i over the i with bit k - q2.  So the 2^q segments are read once to form NI + NJ
+// sums (one wavefront each), and the bit-masked sums run over 128 points instead of 16384: the r02 form read every
+// segment once per bit (14 x 8192 additions on 120 workgroups that held registers the accumulation was waiting for).
+template <class Q>
+ZKT_D XyzzX<Q> wave_sum(XyzzX<Q> acc) {   // valid in lane 0
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        XyzzX<Q> o = xx_shfl_down<Q>(acc, d);
+        if ((threadIdx.x & 63) + d >= 64) o = xx_identity<Q>();
+        acc = xx_add<Q>(acc, o);
+    }
+    return acc;
+}
+
+constexpr int MSM_A_PARTS = 32;  // partial sums of segA (2 segments per thread: the chain is what this stage costs)
+// wavefront w < NI: R_w = sum_j T[w NJ + j];  NI <= w < NI + NJ: C_(w - NI) = sum_i T[i NJ + (w - NI)];
+// the last MSM_A_PARTS workgroups: partial sums of segA.   out: rc[NI + NJ] then apart[MSM_A_PARTS]
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_masked_sums(const Xyzz<typename C::Fq>* segA,
-                                                         const Xyzz<typename C::Fq>* segT, uint32_t nseg, int ny,
-                                                         const Xyzz<typename C::Fq>* top_bucket,
-                                                         Xyzz<typename C::Fq>* partials) {
+__global__ __launch_bounds__(256) void k_msm_rowcol(const Xyzz<typename C::Fq>* segA, const Xyzz<typename C::Fq>* segT,
+                                                    uint32_t q1, uint32_t q2, uint32_t sum_blocks,
+                                                    Xyzz<typename C::Fq>* rc, Xyzz<typename C::Fq>* apart) {
     using Q = typename C::Fq;
-    __shared__ Xyzz<Q> wsum[4];
-    const int y = blockIdx.y;
-    if (y == ny) {
-        if (threadIdx.x == 0)
-            xx_store_ark<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, blockIdx.x == 0 ? xx_load<Q>(top_bucket) : xx_identity<Q>());
+    const uint32_t NI = 1u << q1, NJ = 1u << q2, nseg = NI * NJ;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x >= sum_blocks) {   // a partial sum of segA by a whole workgroup
+        __shared__ Xyzz<Q> wsum[4];
+        const uint32_t part = blockIdx.x - sum_blocks;
+        XyzzX<Q> acc = xx_identity<Q>();
+        for (uint32_t s = part * 256u + threadIdx.x; s < nseg; s += MSM_A_PARTS * 256u) acc = xx_add<Q>(acc, xx_load<Q>(segA + s));
+        acc = block_sum_256<Q>(acc, wsum);
+        if (threadIdx.x == 0) xx_store<Q>(apart + part, acc);
         return;
     }
-    const Xyzz<Q>* src = (y == 0) ? segA : segT;
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (w >= NI + NJ) return;
     XyzzX<Q> acc = xx_identity<Q>();
-    if (y == 0) {
-        for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
-            acc = xx_add<Q>(acc, xx_load<Q>(src + s));
+    if (w < NI) {
+        for (uint32_t j = lane; j < NJ; j += 64) acc = xx_add<Q>(acc, xx_load<Q>(segT + (size_t)w * NJ + j));
     } else {
-        // only the segments whose index has bit k set take part: enumerate THEM (q -> q with a one inserted at bit k),
-        // so that every lane adds on every trip instead of idling through the half that a mask would skip
-        const uint32_t k = (uint32_t)(y - 1), low = (1u << k) - 1u;
-        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nseg / 2; q += gridDim.x * blockDim.x) {
-            const uint32_t s = ((q & ~low) << 1) | (1u << k) | (q & low);
-            if (s < nseg) acc = xx_add<Q>(acc, xx_load<Q>(src + s));
-        }
+        const uint32_t j = w - NI;
+        for (uint32_t i = lane; i < NI; i += 64) acc = xx_add<Q>(acc, xx_load<Q>(segT + (size_t)i * NJ + j));
     }
-    acc = block_sum_256<Q>(acc, wsum);
-    if (threadIdx.x == 0) xx_store_ark<Q>(partials + (size_t)y * gridDim.x + blockIdx.x, acc);
+    acc = wave_sum<Q>(acc);
+    if (lane == 0) xx_store<Q>(rc + w, acc);
+}
+
+// One single-wavefront workgroup per row of the host's table (sixteen of them on one CU took turns at the registers): y = 0: the sum of the segA partial sums; y = k + 1, k < q2:
+// sum of C_j over j with bit k; y = q2 + k + 1, k < q1: sum of R_i over i with bit k; y = ny: the top bucket alone.
+// Written in arkworks' R form straight into pinned host memory: the host applies the weights 2^(e_y)
+// (hostec.hpp weighted_row_sum) -- the remaining ~35 dependent curve operations cost a wavefront 0.6 ms and the host 15 us.
+template <class C>
+__global__ __launch_bounds__(64) void k_msm_weighted_rows(const Xyzz<typename C::Fq>* rc, const Xyzz<typename C::Fq>* apart,
+                                                            uint32_t q1, uint32_t q2, int ny,
+                                                            const Xyzz<typename C::Fq>* top_bucket,
+                                                            Xyzz<typename C::Fq>* partials) {
+    using Q = typename C::Fq;
+    const uint32_t NI = 1u << q1, NJ = 1u << q2;
+    const uint32_t lane = threadIdx.x & 63u;
+    {
+        const int y = (int)blockIdx.x;
+        XyzzX<Q> acc = xx_identity<Q>();
+        if (y == ny) {
+            if (lane == 0) acc = xx_load<Q>(top_bucket);
+        } else if (y == 0) {
+            for (uint32_t t = lane; t < (uint32_t)MSM_A_PARTS; t += 64) acc = xx_add<Q>(acc, xx_load<Q>(apart + t));
+        } else {
+            const bool col = (uint32_t)(y - 1) < q2;
+            const uint32_t k = col ? (uint32_t)(y - 1) : (uint32_t)(y - 1) - q2, low = (1u << k) - 1u;
+            const uint32_t cnt = (col ? NJ : NI) >> 1;
+            const Xyzz<Q>* src = col ? rc + NI : rc;
+            for (uint32_t q = lane; q < cnt; q += 64) {
+                const uint32_t idx = ((q & ~low) << 1) | (1u << k) | (q & low);   // q with a one inserted at bit k
+                acc = xx_add<Q>(acc, xx_load<Q>(src + idx));
+            }
+        }
+        acc = wave_sum<Q>(acc);
+        if (lane == 0) xx_store_ark<Q>(partials + y, acc);
+    }
 }
 
 // table: arkworks R form -> R' form (canonical packed), in place; (0,0) stays (0,0)
@@ -962,6 +1011,11 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segA[i], nseg * sizeof(Xyzz<Q>)))) return rc;
         if ((rc = dev_alloc(c, &st->segT[i], nseg * sizeof(Xyzz<Q>)))) return rc;
+        {   // 2^q1 row sums + 2^q2 column sums (q1 + q2 = log2 nseg) + the partial sums of segA
+            const int q = cb - 1 - MSM_LOG_SEG, q2 = q / 2, q1 = q - q2;
+            const size_t entries = ((size_t)1 << q1) + ((size_t)1 << q2) + MSM_A_PARTS;
+            if ((rc = dev_alloc(c, &st->rowcol[i], entries * sizeof(Xyzz<Q>)))) return rc;
+        }
         ZKT_HIP(c, hipHostMalloc(&st->host_result[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>), hipHostMallocMapped));
         ZKT_HIP(c, hipHostGetDevicePointer(&st->host_result_dev[i], st->host_result[i], 0));
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
@@ -998,7 +1052,7 @@ void msm_release(zkt_ctx* c) {
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]);
-        dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]);
+        dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]); dev_free(c, st.rowcol[i]);
     }
     c->msm.reset();
 }
@@ -1159,13 +1213,21 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
                        (const Xyzz<Q>*)st.buckets[slot], nseg, (Xyzz<Q>*)st.segA[slot], (Xyzz<Q>*)st.segT[slot]);
     ZKT_HIP(c, hipGetLastError());
     ny = msm_rows(st.c);
-    hipLaunchKernelGGL(k_msm_masked_sums<C>, dim3(MSM_R2_BLOCKS, ny + 1), dim3(256), 0, st.side,
-                       (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], nseg, ny,
-                       (const Xyzz<Q>*)st.buckets[slot] + st.B, (Xyzz<Q>*)st.host_result_dev[slot]);
-    ZKT_HIP(c, hipGetLastError());
+    {
+        const uint32_t q = (uint32_t)(st.c - 1 - MSM_LOG_SEG), q2 = q / 2, q1 = q - q2;   // nseg = 2^q = 2^q1 rows x 2^q2 columns
+        const uint32_t sums = (1u << q1) + (1u << q2), sum_blocks = (sums + 3) / 4;
+        Xyzz<Q>* rc = (Xyzz<Q>*)st.rowcol[slot];
+        hipLaunchKernelGGL(k_msm_rowcol<C>, dim3(sum_blocks + MSM_A_PARTS), dim3(256), 0, st.side,
+                           (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], q1, q2, sum_blocks, rc, rc + sums);
+        ZKT_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k_msm_weighted_rows<C>, dim3(ny + 1), dim3(64), 0, st.side, (const Xyzz<Q>*)rc,
+                           (const Xyzz<Q>*)(rc + sums), q1, q2, ny, (const Xyzz<Q>*)st.buckets[slot] + st.B,
+                           (Xyzz<Q>*)st.host_result_dev[slot]);
+        ZKT_HIP(c, hipGetLastError());
     }
-    // the (ny + 1) x R2_BLOCKS partial sums are written straight into pinned host memory (129 posted writes of 128 B;
-    // a copy engine took ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
+    }
+    // the ny + 1 row sums are written straight into pinned host memory (16 posted writes of 128 B; a copy engine took
+    // ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
     ZKT_HIP(c, hipEventRecord(st.ev_done[slot], st.side));
     st.pending[slot] = true;
     return ZKT_OK;
