@@ -12,8 +12,8 @@
 //  * (bucket, table index) pairs are grouped by bucket with a two-level counting sort (below); accumulation walks
 //    the grouped indices in fixed-size chunks (perfect lane balance whatever the digit distribution), emitting one
 //    partial XYZZ sum per (chunk, bucket) piece at slot chunk + bucket; a second kernel folds a bucket's pieces.
-//  * sum_b b * B_b is computed with short per-thread running sums (segments of 8 buckets), masked
-//    wave/block tree reductions for the segment weights and a final doubling step.
+//  * sum_b b * B_b goes through the row and column sums of the bucket matrix (one wavefront per sum), then one
+//    single-wave workgroup per bit of b; the last doublings run on the host.
 //  * The single resulting point is normalised (one inversion) on the host, which needs the affine
 //    coordinates for the Fiat-Shamir transcript anyway.
 //  * The prover's scalars are polynomial coefficients in arkworks' Montgomery form a = s R mod r.  The table holds
@@ -33,8 +33,6 @@ namespace zkt {
 
 constexpr int MSM_CHUNK_MIN = 16;  // grouped pairs per accumulation thread: at least this many; the actual
                                    // chunk is sized so that ONE resident wave-front of threads covers the array
-constexpr int MSM_LOG_SEG = 2;
-constexpr int MSM_SEG = 1 << MSM_LOG_SEG;   // buckets per running-sum segment
 constexpr int MSM_R2_BLOCKS = 1;     // partial sums per row handed to the host
 constexpr int MSM_MAX_Y = 24;
 
@@ -81,9 +79,7 @@ struct MsmState {
     // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
     static constexpr int SLOTS = 11;
     void* buckets[SLOTS] = {};      // Xyzz[B + 1]
-    void* segA[SLOTS] = {};         // Xyzz[B / SEG]
-    void* segT[SLOTS] = {};
-    void* rowcol[SLOTS] = {};       // Xyzz[NI + NJ + MSM_A_PARTS]: row / column sums of segT, partial sums of segA
+    void* rowcol[SLOTS] = {};       // Xyzz[NI + NJ]: row / column sums of the bucket matrix
     void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
     void* host_result_dev[SLOTS] = {};  // the same memory as the kernels address it
     size_t acc_threads = 196608;   // chunks an MSM is cut into: resident threads of k_msm_accumulate (occupancy query) x 2
@@ -775,32 +771,14 @@ __global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// bucket reduction  S = sum_{b=0..B} b * bucket[b]
-//   = 2^(c-1) * bucket[B] + sum_s A_s + SEG * sum_s s * T_s      (s over segments of SEG buckets)
+// bucket reduction  S = sum_{b=0..B} b * bucket[b] = 2^(c-1) * bucket[B] + sum_k 2^k * (sum of bucket[b] over b < B with bit k)
+// through row and column sums: with b = i NJ + j (NJ = 2^q2 columns, NI = 2^q1 rows, q1 + q2 = c - 1) the sum of the
+// buckets whose bit k is set equals the sum of the COLUMN sums C_j over the j with bit k (k < q2), or of the ROW sums
+// R_i over the i with bit k - q2.  So the 2^(c-1) buckets are read twice to form NI + NJ sums (one wavefront each), and
+// the bit-weighted sums run over 2^q1 + 2^q2 = 512 points instead of 65536.  r02 went through 4-bucket running sums
+// and then read every segment once per bit (14 x 8192 additions on 120 workgroups that held registers the accumulation
+// was waiting for): seven times the additions, four times the waves, ten dependent additions more.
 // ---------------------------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(256) void k_msm_segments(const Xyzz<typename C::Fq>* buckets, uint32_t nseg,
-                                                      Xyzz<typename C::Fq>* segA, Xyzz<typename C::Fq>* segT) {
-    using Q = typename C::Fq;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nseg) return;
-    const Xyzz<Q>* a = buckets + (size_t)s * MSM_SEG;
-    XyzzX<Q> run = xx_identity<Q>(), acc = xx_identity<Q>();
-#pragma unroll 1
-    for (int j = MSM_SEG - 1; j >= 1; --j) {
-        run = xx_add<Q>(run, xx_load<Q>(a + j));
-        acc = xx_add<Q>(acc, run);
-    }
-    run = xx_add<Q>(run, xx_load<Q>(a));
-    xx_store<Q>(segA + s, acc);
-    xx_store<Q>(segT + s, run);
-}
-
-// The weighted sum over segments, sum_s s T_s, through row and column sums: with s = i NJ + j (NJ = 2^q2 columns,
-// NI = 2^q1 rows) the sum of T_s over the s whose bit k is set equals the sum of the COLUMN sums C_j over the j with bit k
-// (k < q2), or of the ROW sums R_i over the i with bit k - q2.  So the 2^q segments are read once to form NI + NJ
-// sums (one wavefront each), and the bit-masked sums run over 128 points instead of 16384: the r02 form read every
-// segment once per bit (14 x 8192 additions on 120 workgroups that held registers the accumulation was waiting for).
 template <class Q>
 ZKT_D XyzzX<Q> wave_sum(XyzzX<Q> acc) {   // valid in lane 0
 #pragma unroll 1
@@ -812,70 +790,53 @@ ZKT_D XyzzX<Q> wave_sum(XyzzX<Q> acc) {   // valid in lane 0
     return acc;
 }
 
-constexpr int MSM_A_PARTS = 32;  // partial sums of segA (2 segments per thread: the chain is what this stage costs)
-// wavefront w < NI: R_w = sum_j T[w NJ + j];  NI <= w < NI + NJ: C_(w - NI) = sum_i T[i NJ + (w - NI)];
-// the last MSM_A_PARTS workgroups: partial sums of segA.   out: rc[NI + NJ] then apart[MSM_A_PARTS]
+// wavefront w < NI: R_w = sum_j bucket[w NJ + j];  NI <= w < NI + NJ: C_(w - NI) = sum_i bucket[i NJ + (w - NI)]
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_rowcol(const Xyzz<typename C::Fq>* segA, const Xyzz<typename C::Fq>* segT,
-                                                    uint32_t q1, uint32_t q2, uint32_t sum_blocks,
-                                                    Xyzz<typename C::Fq>* rc, Xyzz<typename C::Fq>* apart) {
+__global__ __launch_bounds__(256) void k_msm_rowcol(const Xyzz<typename C::Fq>* buckets, uint32_t q1, uint32_t q2,
+                                                    Xyzz<typename C::Fq>* rc) {
     using Q = typename C::Fq;
-    const uint32_t NI = 1u << q1, NJ = 1u << q2, nseg = NI * NJ;
+    const uint32_t NI = 1u << q1, NJ = 1u << q2;
     const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.x >= sum_blocks) {   // a partial sum of segA by a whole workgroup
-        __shared__ Xyzz<Q> wsum[4];
-        const uint32_t part = blockIdx.x - sum_blocks;
-        XyzzX<Q> acc = xx_identity<Q>();
-        for (uint32_t s = part * 256u + threadIdx.x; s < nseg; s += MSM_A_PARTS * 256u) acc = xx_add<Q>(acc, xx_load<Q>(segA + s));
-        acc = block_sum_256<Q>(acc, wsum);
-        if (threadIdx.x == 0) xx_store<Q>(apart + part, acc);
-        return;
-    }
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (w >= NI + NJ) return;
     XyzzX<Q> acc = xx_identity<Q>();
     if (w < NI) {
-        for (uint32_t j = lane; j < NJ; j += 64) acc = xx_add<Q>(acc, xx_load<Q>(segT + (size_t)w * NJ + j));
+        for (uint32_t j = lane; j < NJ; j += 64) acc = xx_add<Q>(acc, xx_load<Q>(buckets + (size_t)w * NJ + j));
     } else {
         const uint32_t j = w - NI;
-        for (uint32_t i = lane; i < NI; i += 64) acc = xx_add<Q>(acc, xx_load<Q>(segT + (size_t)i * NJ + j));
+        for (uint32_t i = lane; i < NI; i += 64) acc = xx_add<Q>(acc, xx_load<Q>(buckets + (size_t)i * NJ + j));
     }
     acc = wave_sum<Q>(acc);
     if (lane == 0) xx_store<Q>(rc + w, acc);
 }
 
-// One single-wavefront workgroup per row of the host's table (sixteen of them on one CU took turns at the registers): y = 0: the sum of the segA partial sums; y = k + 1, k < q2:
-// sum of C_j over j with bit k; y = q2 + k + 1, k < q1: sum of R_i over i with bit k; y = ny: the top bucket alone.
-// Written in arkworks' R form straight into pinned host memory: the host applies the weights 2^(e_y)
+// One single-wavefront workgroup per row of the host's table (sixteen of them on one CU took turns at the registers):
+// y = k < q2: sum of C_j over j with bit k; y = q2 + k, k < q1: sum of R_i over i with bit k; y = q1 + q2: the top bucket
+// alone.  Written in arkworks' R form straight into pinned host memory: the host applies the weights 2^y
 // (hostec.hpp weighted_row_sum) -- the remaining ~35 dependent curve operations cost a wavefront 0.6 ms and the host 15 us.
 template <class C>
-__global__ __launch_bounds__(64) void k_msm_weighted_rows(const Xyzz<typename C::Fq>* rc, const Xyzz<typename C::Fq>* apart,
-                                                            uint32_t q1, uint32_t q2, int ny,
-                                                            const Xyzz<typename C::Fq>* top_bucket,
-                                                            Xyzz<typename C::Fq>* partials) {
+__global__ __launch_bounds__(64) void k_msm_weighted_rows(const Xyzz<typename C::Fq>* rc, uint32_t q1, uint32_t q2,
+                                                          const Xyzz<typename C::Fq>* top_bucket,
+                                                          Xyzz<typename C::Fq>* partials) {
     using Q = typename C::Fq;
     const uint32_t NI = 1u << q1, NJ = 1u << q2;
     const uint32_t lane = threadIdx.x & 63u;
-    {
-        const int y = (int)blockIdx.x;
-        XyzzX<Q> acc = xx_identity<Q>();
-        if (y == ny) {
-            if (lane == 0) acc = xx_load<Q>(top_bucket);
-        } else if (y == 0) {
-            for (uint32_t t = lane; t < (uint32_t)MSM_A_PARTS; t += 64) acc = xx_add<Q>(acc, xx_load<Q>(apart + t));
-        } else {
-            const bool col = (uint32_t)(y - 1) < q2;
-            const uint32_t k = col ? (uint32_t)(y - 1) : (uint32_t)(y - 1) - q2, low = (1u << k) - 1u;
-            const uint32_t cnt = (col ? NJ : NI) >> 1;
-            const Xyzz<Q>* src = col ? rc + NI : rc;
-            for (uint32_t q = lane; q < cnt; q += 64) {
-                const uint32_t idx = ((q & ~low) << 1) | (1u << k) | (q & low);   // q with a one inserted at bit k
-                acc = xx_add<Q>(acc, xx_load<Q>(src + idx));
-            }
+    const uint32_t y = blockIdx.x;
+    XyzzX<Q> acc = xx_identity<Q>();
+    if (y == q1 + q2) {
+        if (lane == 0) acc = xx_load<Q>(top_bucket);
+    } else {
+        const bool col = y < q2;
+        const uint32_t k = col ? y : y - q2, low = (1u << k) - 1u;
+        const uint32_t cnt = (col ? NJ : NI) >> 1;
+        const Xyzz<Q>* src = col ? rc + NI : rc;
+        for (uint32_t q = lane; q < cnt; q += 64) {
+            const uint32_t idx = ((q & ~low) << 1) | (1u << k) | (q & low);   // q with a one inserted at bit k
+            acc = xx_add<Q>(acc, xx_load<Q>(src + idx));
         }
-        acc = wave_sum<Q>(acc);
-        if (lane == 0) xx_store_ark<Q>(partials + y, acc);
     }
+    acc = wave_sum<Q>(acc);
+    if (lane == 0) xx_store_ark<Q>(partials + y, acc);
 }
 
 // table: arkworks R form -> R' form (canonical packed), in place; (0,0) stays (0,0)
@@ -894,8 +855,8 @@ __global__ void k_srs_to_fx(Affine<typename C::Fq>* table, size_t total) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// rows of partial sums an MSM leaves for the host: row 0 (weight 1), one row per bit of the segment index, the top bucket
-static int msm_rows(int c) { return 1 + (c - 1 - MSM_LOG_SEG); }
+// rows of partial sums an MSM leaves for the host besides the top bucket's: one per bit of the bucket index below B
+static int msm_rows(int c) { return c - 1; }
 
 static int floor_log2(size_t x) {
     int l = 0;
@@ -998,23 +959,12 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     for (int i = 0; i < MsmState::SLOTS; ++i)
         if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
-    size_t nseg = st->B / MSM_SEG;
-    {
-        int lo = 0, hi = 0;   // numerically lower = higher priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* e = getenv("ZKT_MSM_SIDE_PRIO");
-        if (e && !strcmp(e, "hi")) ZKT_HIP(c, hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, hi));
-        else if (e && !strcmp(e, "lo")) ZKT_HIP(c, hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, lo));
-        else ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
-    }
+    ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
-        if ((rc = dev_alloc(c, &st->segA[i], nseg * sizeof(Xyzz<Q>)))) return rc;
-        if ((rc = dev_alloc(c, &st->segT[i], nseg * sizeof(Xyzz<Q>)))) return rc;
-        {   // 2^q1 row sums + 2^q2 column sums (q1 + q2 = log2 nseg) + the partial sums of segA
-            const int q = cb - 1 - MSM_LOG_SEG, q2 = q / 2, q1 = q - q2;
-            const size_t entries = ((size_t)1 << q1) + ((size_t)1 << q2) + MSM_A_PARTS;
-            if ((rc = dev_alloc(c, &st->rowcol[i], entries * sizeof(Xyzz<Q>)))) return rc;
+        {   // 2^q1 row sums + 2^q2 column sums of the bucket matrix (q1 + q2 = c - 1)
+            const int q = cb - 1, q2 = q / 2, q1 = q - q2;
+            if ((rc = dev_alloc(c, &st->rowcol[i], (((size_t)1 << q1) + ((size_t)1 << q2)) * sizeof(Xyzz<Q>)))) return rc;
         }
         ZKT_HIP(c, hipHostMalloc(&st->host_result[i], (size_t)(MSM_MAX_Y + 1) * MSM_R2_BLOCKS * sizeof(Xyzz<Q>), hipHostMallocMapped));
         ZKT_HIP(c, hipHostGetDevicePointer(&st->host_result_dev[i], st->host_result[i], 0));
@@ -1052,7 +1002,7 @@ void msm_release(zkt_ctx* c) {
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]);
-        dev_free(c, st.buckets[i]); dev_free(c, st.segA[i]); dev_free(c, st.segT[i]); dev_free(c, st.rowcol[i]);
+        dev_free(c, st.buckets[i]); dev_free(c, st.rowcol[i]);
     }
     c->msm.reset();
 }
@@ -1192,7 +1142,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         ZKT_HIP(c, hipGetLastError());
     }
     }
-    // ---- tail on the side stream: the bucket fold (latency bound: one wave per SIMD, three dependent additions) and the
+    // ---- tail on the side stream: the bucket fold (latency bound: one wave per SIMD, a few dependent additions) and the
     // bucket reduction overlap whatever the main stream does next; everything they read is the slot's own ----
     ZKT_HIP(c, hipEventRecord(st.ev_main[slot], c->stream));
     ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[slot], 0));
@@ -1205,26 +1155,16 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
                        (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
     ZKT_HIP(c, hipGetLastError());
     }
-    int ny = 0;
     {
     ProfScope prof_tail(c, "msm_tail", st.side);
-    const uint32_t nseg = st.B / MSM_SEG;
-    hipLaunchKernelGGL(k_msm_segments<C>, dim3((nseg + 255) / 256), dim3(256), 0, st.side,
-                       (const Xyzz<Q>*)st.buckets[slot], nseg, (Xyzz<Q>*)st.segA[slot], (Xyzz<Q>*)st.segT[slot]);
+    const uint32_t q = (uint32_t)(st.c - 1), q2 = q / 2, q1 = q - q2;   // 2^q buckets below B = 2^q1 rows x 2^q2 columns
+    const uint32_t sums = (1u << q1) + (1u << q2);
+    Xyzz<Q>* rc = (Xyzz<Q>*)st.rowcol[slot];
+    hipLaunchKernelGGL(k_msm_rowcol<C>, dim3((sums + 3) / 4), dim3(256), 0, st.side, (const Xyzz<Q>*)st.buckets[slot], q1, q2, rc);
     ZKT_HIP(c, hipGetLastError());
-    ny = msm_rows(st.c);
-    {
-        const uint32_t q = (uint32_t)(st.c - 1 - MSM_LOG_SEG), q2 = q / 2, q1 = q - q2;   // nseg = 2^q = 2^q1 rows x 2^q2 columns
-        const uint32_t sums = (1u << q1) + (1u << q2), sum_blocks = (sums + 3) / 4;
-        Xyzz<Q>* rc = (Xyzz<Q>*)st.rowcol[slot];
-        hipLaunchKernelGGL(k_msm_rowcol<C>, dim3(sum_blocks + MSM_A_PARTS), dim3(256), 0, st.side,
-                           (const Xyzz<Q>*)st.segA[slot], (const Xyzz<Q>*)st.segT[slot], q1, q2, sum_blocks, rc, rc + sums);
-        ZKT_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_msm_weighted_rows<C>, dim3(ny + 1), dim3(64), 0, st.side, (const Xyzz<Q>*)rc,
-                           (const Xyzz<Q>*)(rc + sums), q1, q2, ny, (const Xyzz<Q>*)st.buckets[slot] + st.B,
-                           (Xyzz<Q>*)st.host_result_dev[slot]);
-        ZKT_HIP(c, hipGetLastError());
-    }
+    hipLaunchKernelGGL(k_msm_weighted_rows<C>, dim3(q + 1), dim3(64), 0, st.side, (const Xyzz<Q>*)rc, q1, q2,
+                       (const Xyzz<Q>*)st.buckets[slot] + st.B, (Xyzz<Q>*)st.host_result_dev[slot]);
+    ZKT_HIP(c, hipGetLastError());
     }
     // the ny + 1 row sums are written straight into pinned host memory (16 posted writes of 128 B; a copy engine took
     // ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
@@ -1233,15 +1173,13 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     return ZKT_OK;
 }
 
-// S = sum_y 2^(e_y) V_y : V_0 = sum of segA (e = 0), V_(k+1) = sum of segT over segments with bit k (e = k + LOG_SEG),
-// the top bucket (e = c - 1).  ~150 curve operations on 64-bit limbs.
+// S = sum_y 2^y V_y : V_y = the sum of the buckets below B whose index has bit y (y < c - 1), V_(c-1) = the top bucket.
+// ~50 curve operations on 64-bit limbs.
 template <class Q>
 static Xyzz<Q> msm_host_finish(const MsmState& st, int slot) {
     const int ny = msm_rows(st.c);
     int exps[MSM_MAX_Y + 1];
-    exps[0] = 0;
-    for (int y = 1; y < ny; ++y) exps[y] = (y - 1) + MSM_LOG_SEG;
-    exps[ny] = st.c - 1;
+    for (int y = 0; y <= ny; ++y) exps[y] = y;
     return hostec::weighted_row_sum<Q>((const Xyzz<Q>*)st.host_result[slot], ny + 1, MSM_R2_BLOCKS, exps);
 }
 
