@@ -46,6 +46,24 @@ KERNEL(k_fma_f64, DECL_F64, OP8("v_fma_f64 %0, %0, %1, %2", "v"(b) COMMA "v"(c))
 KERNEL(k_fma_f32, DECL_U32, OP8("v_fma_f32 %0, %0, %1, %1", "v"(b)), SINK_U32)
 KERNEL(k_mad_i32_i24, DECL_U32, OP8("v_mad_i32_i24 %0, %0, %1, %1", "v"(b)), SINK_U32)
 KERNEL(k_cndmask, DECL_U32, OP8("v_cndmask_b32 %0, %0, %1, vcc", "v"(b)), SINK_U32)
+KERNEL(k_and_b32, DECL_U32, OP8("v_and_b32 %0, %0, %1", "v"(b)), SINK_U32)
+KERNEL(k_and_imm, DECL_U32, OP8("v_and_b32 %0, 0x1fffffff, %0", "v"(b)), SINK_U32)
+KERNEL(k_lshrrev_b32, DECL_U32, OP8("v_lshrrev_b32 %0, 1, %0", "v"(b)), SINK_U32)
+KERNEL(k_ashrrev_i32, DECL_U32, OP8("v_ashrrev_i32 %0, 1, %0", "v"(b)), SINK_U32)
+KERNEL(k_sub_u32, DECL_U32, OP8("v_sub_u32 %0, %0, %1", "v"(b)), SINK_U32)
+KERNEL(k_alignbit, DECL_U32, OP8("v_alignbit_b32 %0, %0, %1, 29", "v"(b)), SINK_U32)
+KERNEL(k_and_or, DECL_U32, OP8("v_and_or_b32 %0, %0, %1, %1", "v"(b)), SINK_U32)
+KERNEL(k_bfe_u32, DECL_U32, OP8("v_bfe_u32 %0, %0, 1, 29", "v"(b)), SINK_U32)
+KERNEL(k_lshl_add_u32, DECL_U32, OP8("v_lshl_add_u32 %0, %0, 1, %1", "v"(b)), SINK_U32)
+KERNEL(k_lshrrev_b64, DECL_U64, OP8("v_lshrrev_b64 %0, 1, %0", "v"(b)), SINK_U64)
+KERNEL(k_mad_sgpr, DECL_U64, OP8("v_mad_u64_u32 %0, vcc, %1, %2, %0", "v"(b) COMMA "s"(c) : "vcc"), SINK_U64)
+#define DEP8(ASM, CONS)  \
+    asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a0) : CONS); \
+    asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a0) : CONS);
+KERNEL(k_mad_dep, DECL_U64, DEP8("v_mad_u64_u32 %0, vcc, %1, %2, %0", "v"(b) COMMA "v"(c) : "vcc"), SINK_U64)
+KERNEL(k_mad_dep_grp, DECL_U64, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0\nv_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a0) : "v"(b) COMMA "v"(c) : "vcc");, SINK_U64)
+KERNEL(k_mad_dep2, DECL_U64, asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\nv_mad_u64_u32 %1, vcc, %2, %3, %1\nv_mad_u64_u32 %0, vcc, %2, %3, %0\nv_mad_u64_u32 %1, vcc, %2, %3, %1\nv_mad_u64_u32 %0, vcc, %2, %3, %0\nv_mad_u64_u32 %1, vcc, %2, %3, %1\nv_mad_u64_u32 %0, vcc, %2, %3, %0\nv_mad_u64_u32 %1, vcc, %2, %3, %1" : "+v"(a0) COMMA "+v"(a1) : "v"(b) COMMA "v"(c) : "vcc");, SINK_U64)
+KERNEL(k_mov_b64, DECL_U64, OP8("v_mov_b64 %0, %1", "v"((uint64_t)b)), SINK_U64)
 
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; };
@@ -62,7 +80,11 @@ int main() {
                   {"v_add_u32", k_add_u32}, {"v_add_co_u32", k_add_co_u32}, {"v_addc_co_u32", k_addc_co_u32},
                   {"v_add3_u32", k_add3_u32}, {"v_mov_b32", k_mov_b32}, {"v_lshl_add_u64", k_lshl_add_u64},
                   {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24}, {"v_mad_i32_i24", k_mad_i32_i24},
-                  {"v_fma_f64", k_fma_f64}, {"v_fma_f32", k_fma_f32}, {"v_cndmask_b32", k_cndmask}};
+                  {"v_fma_f64", k_fma_f64}, {"v_fma_f32", k_fma_f32}, {"v_cndmask_b32", k_cndmask},
+                  {"v_and_b32", k_and_b32}, {"v_and_b32 imm", k_and_imm}, {"v_lshrrev_b32", k_lshrrev_b32}, {"v_ashrrev_i32", k_ashrrev_i32},
+                  {"v_sub_u32", k_sub_u32}, {"v_alignbit_b32", k_alignbit}, {"v_and_or_b32", k_and_or}, {"v_bfe_u32", k_bfe_u32},
+                  {"v_lshl_add_u32", k_lshl_add_u32}, {"v_lshrrev_b64", k_lshrrev_b64}, {"v_mad_u64 sgpr", k_mad_sgpr}, {"v_mov_b64", k_mov_b64},
+                  {"mad dep+nop", k_mad_dep}, {"mad dep grouped", k_mad_dep_grp}, {"mad 2 chains", k_mad_dep2}};
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));

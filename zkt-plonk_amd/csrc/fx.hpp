@@ -14,6 +14,7 @@
 // which makes fx_mul(unpack(a~), unpack_shift(b~)) return (ab)~ in arkworks' own Montgomery form.
 #pragma once
 #include "fp.hpp"
+#include <utility>
 
 namespace zkt {
 
@@ -308,9 +309,100 @@ struct FxVec {
     typedef uint32_t type __attribute__((ext_vector_type(FxP<P>::L)));
 };
 
+// The device products below issue their multiply-adds through opaque statements: left to itself the compiler
+// starts every column from zero and then ADDS the shifted carry of the previous one (a v_lshl_add_u64 per column, 7 %
+// of the MSM accumulation loop); v_mad_u64_u32 takes the carry as its addend for free when the chain is kept in order.
+// One operand may be a scalar register (the modulus limbs are compile-time constants).
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fx_madrow.inc"
+__device__ __forceinline__ uint64_t fx_mad0(uint32_t a, uint32_t b) {
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+}
+template <int N, bool K>
+__device__ __forceinline__ void fx_mad_rows(uint64_t& acc, const uint32_t* x, const uint32_t* y) {
+    if constexpr (N > 14) {
+        fx_mad_rows<14, K>(acc, x, y);
+        fx_mad_rows<N - 14, K>(acc, x + 14, y + 14);
+    } else if constexpr (N > 0) {
+        if constexpr (K) MadRow<N>::vk(acc, x, y);
+        else MadRow<N>::vv(acc, x, y);
+    }
+}
+
+// Column COL of (a * b [+ c * d]) / R' in product-scanning order (SQR: b == a, cross terms once against the doubled
+// operand a2): the operand products as one chain, the reduction products m[i] * p[j] as another.
+template <class P, bool TWO, bool SQR, int COL>
+__device__ __forceinline__ void fx_mont_column(uint64_t& acc, uint32_t* m, Fx<P>& r, const uint32_t* a, const uint32_t* b,
+                                               const uint32_t* c, const uint32_t* d, const uint32_t* a2) {
+    constexpr int L = FxP<P>::L;
+    constexpr int lo = COL < L ? 0 : COL - L + 1, hi = COL < L ? COL : L - 1;     // i + j = COL, both below L
+    constexpr int terms = hi - lo + 1;
+    constexpr int nv = SQR ? (terms + 1) / 2 : (TWO ? 2 * terms : terms);
+    constexpr int skip = COL == 0 ? 1 : 0;                                         // a0 * b0 started the accumulator
+    uint32_t x[nv + 1], y[nv + 1];
+    int n = 0;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+        const int j = COL - i;
+        if (SQR) {
+            if (j > i) { x[n] = a2[i]; y[n] = a[j]; ++n; }
+            else if (j == i) { x[n] = a[i]; y[n] = a[i]; ++n; }
+        } else {
+            x[n] = a[i]; y[n] = b[j]; ++n;
+            if (TWO) { x[n] = c[i]; y[n] = d[j]; ++n; }
+        }
+    }
+    fx_mad_rows<nv - skip, false>(acc, x + skip, y + skip);
+    constexpr int rlo = lo, rhi = COL < L ? COL - 1 : L - 1;                        // m[i] * p[COL - i], COL - i >= 1
+    constexpr int nk = rhi - rlo + 1;
+    if constexpr (nk > 0) {
+        uint32_t xm[nk], yk[nk];
+#pragma unroll
+        for (int t = 0; t < nk; ++t) {
+            xm[t] = m[rlo + t];
+            yk[t] = FxP<P>::mod(COL - rlo - t);
+        }
+        fx_mad_rows<nk, true>(acc, xm, yk);
+    }
+    if constexpr (COL < L) {
+        m[COL] = ((uint32_t)acc * FxP<P>::INV) & FxP<P>::MASK;
+        const uint32_t p0 = FxP<P>::mod(0);
+        MadRow<1>::vk(acc, &m[COL], &p0);
+    } else {
+        r.l[COL - L] = (uint32_t)acc & FxP<P>::MASK;
+    }
+    acc >>= 29;
+}
+
+template <class P, bool TWO, bool SQR, int... COLS>
+__device__ __forceinline__ Fx<P> fx_mont_chain_seq(const Fx<P>& a, const Fx<P>& b, const Fx<P>& c, const Fx<P>& d,
+                                                   std::integer_sequence<int, COLS...>) {
+    constexpr int L = FxP<P>::L;
+    uint32_t m[L], a2[L];
+    if (SQR) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) a2[i] = a.l[i] << 1;
+    }
+    Fx<P> r;
+    uint64_t acc = fx_mad0(a.l[0], SQR ? a.l[0] : b.l[0]);
+    (fx_mont_column<P, TWO, SQR, COLS>(acc, m, r, a.l, b.l, c.l, d.l, a2), ...);
+    r.l[L - 1] = (uint32_t)acc;
+    return r;
+}
+template <class P, bool TWO, bool SQR>
+__device__ __forceinline__ Fx<P> fx_mont_chain(const Fx<P>& a, const Fx<P>& b, const Fx<P>& c, const Fx<P>& d) {
+    return fx_mont_chain_seq<P, TWO, SQR>(a, b, c, d, std::make_integer_sequence<int, 2 * FxP<P>::L - 1>());
+}
+#endif
+
 // fully inlined product (for the one or two loops that are hot enough to own a private copy)
 template <class P>
 ZKT_HD Fx<P> fx_mul_inl(const Fx<P>& a, const Fx<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fx_mont_chain<P, false, false>(a, b, a, b);
+#else
     constexpr int L = FxP<P>::L;
     uint64_t t[L + 1];
 #pragma unroll
@@ -338,12 +430,16 @@ ZKT_HD Fx<P> fx_mul_inl(const Fx<P>& a, const Fx<P>& b) {
     }
     r.l[L - 1] = (uint32_t)(t[L - 1] + c);
     return r;
+#endif
 }
 
 // a^2 / R' with the cross products taken once against the doubled operand: L(L+1)/2 + L^2 multiply-adds.
 // Same contract as fx_mul_inl (a * a < R' * p, limbs < 2^29).
 template <class P>
 ZKT_HD Fx<P> fx_sqr_inl(const Fx<P>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fx_mont_chain<P, false, true>(a, a, a, a);
+#else
     constexpr int L = FxP<P>::L;
     uint32_t a2[L], m[L];
 #pragma unroll
@@ -375,12 +471,16 @@ ZKT_HD Fx<P> fx_sqr_inl(const Fx<P>& a) {
     }
     r.l[L - 1] = (uint32_t)acc;
     return r;
+#endif
 }
 
 // (a * b + c * d) / R' with one reduction: 3 L^2 multiply-adds instead of 4 L^2.
 // Needs a * b + c * d < R' * p and limbs < 2^29; returns normalised limbs, value < 2p.
 template <class P>
 ZKT_HD Fx<P> fx_mul2_inl(const Fx<P>& a, const Fx<P>& b, const Fx<P>& c, const Fx<P>& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fx_mont_chain<P, true, false>(a, b, c, d);
+#else
     constexpr int L = FxP<P>::L;
     uint32_t m[L];
     Fx<P> r;
@@ -406,6 +506,7 @@ ZKT_HD Fx<P> fx_mul2_inl(const Fx<P>& a, const Fx<P>& b, const Fx<P>& c, const F
     }
     r.l[L - 1] = (uint32_t)acc;
     return r;
+#endif
 }
 
 template <class P>
