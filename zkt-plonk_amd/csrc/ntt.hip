@@ -87,7 +87,7 @@ ZKT_D void dif_group(Fx<P>* x, const W& w, int off, int sub, int L) {
                     else if (l == 1) d = fx_sub_lazy<P, 5>(u, v);
                     else d = fx_sub_lazy<P, 9>(u, v);
                     const int e = ((i & (h - 1)) * sub + off) << (L + l);
-                    x[i + h] = fx_mul<P>(w.get(e), d);
+                    x[i + h] = fx_mul_inl<P>(w.get(e), d);
                 }
             }
         }
