@@ -82,6 +82,7 @@ struct MsmState {
     void* rowcol[SLOTS] = {};       // Xyzz[NI + NJ]: row / column sums of the bucket matrix
     void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
     void* host_result_dev[SLOTS] = {};  // the same memory as the kernels address it
+    size_t acc_lds = 0;            // dynamic LDS of k_msm_accumulate (0; ZKT_MSM_ACC_LDS caps its residency in experiments)
     size_t acc_threads = 196608;   // chunks an MSM is cut into: resident threads of k_msm_accumulate (occupancy query) x 2
     hipStream_t side = nullptr;
     hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
@@ -938,7 +939,11 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         int blocks_per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_msm_accumulate<C>, 256, 0) == hipSuccess &&
+        if (const char* e = getenv("ZKT_MSM_ACC_LDS")) {   // experiment: cap the resident workgroups through dynamic LDS
+            st->acc_lds = (size_t)atoi(e) * 1024;
+            (void)hipFuncSetAttribute((const void*)k_msm_accumulate<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->acc_lds);
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_msm_accumulate<C>, 256, st->acc_lds) == hipSuccess &&
             blocks_per_cu > 0 && cus > 0)
             st->acc_threads = (size_t)blocks_per_cu * cus * 256;
         // Twice as many chunks as the chip keeps resident: the bucket reduction of the previous MSM runs on the side stream
@@ -1137,7 +1142,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     {
         ProfScope prof_acc(c, "msm_accumulate");
         uint32_t max_chunks = (m + chunk - 1) / chunk;
-        hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), 0, c->stream, st.vals2,
+        hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), st.acc_lds, c->stream, st.vals2,
                            st.B, chunk, st.offsets[slot], st.chunk_bucket, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces[slot]);
         ZKT_HIP(c, hipGetLastError());
     }
