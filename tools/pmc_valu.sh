@@ -39,5 +39,4 @@ with open("gpurun_out/pmc_valu_%s.txt" % sys.argv[1], "w") as fo:
         busy = g("SQ_BUSY_CYCLES")
         if busy and valu:
             fo.write("    -> SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.3f\n" % (valu / busy))
-print(open("gpurun_out/pmc_valu_%s.txt" % sys.argv[1]).read())
 PY
