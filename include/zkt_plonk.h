@@ -342,6 +342,17 @@ int zkt_pairing_product_is_one(int curve_id, const uint64_t* g1_xy_mont, const u
 int zkt_verify(int curve_id, const zkt_verify_inputs* in, zkt_transcript* transcript, const uint64_t* h_g2_mont,
                const uint64_t* beta_h_g2_mont, int* accepted);
 
+/* `count` proofs under ONE structured reference string (h, beta h), circuits / verifier keys free to differ: each proof is
+ * taken through zkt_verify_prepare with its own seeded transcript, and all 2 * count opening checks are folded into ONE
+ * product of two pairings with 128-bit coefficients hashed from every (L, W), h and beta h (see csrc/verify.hip).
+ * *accepted = 1 iff every proof verifies (a batch holding a bad proof passes with probability 2^-128); a rejected batch
+ * does not say which proof failed -- fall back to zkt_verify.  Cost per proof: the transcript, r0 and the two short
+ * multi-scalar multiplications; the pairings (~0.5 ms on BN254) are paid once per batch.  The reference verifies proof by
+ * proof (proof.rs:285-503); this is the batch form SURVEY.md 8f.4 lists.  Errors as zkt_verify_prepare (a malformed
+ * proof fails the call, not just the batch). */
+int zkt_verify_batch(int curve_id, const zkt_verify_inputs* ins, zkt_transcript* const* transcripts, size_t count,
+                     const uint64_t* h_g2_mont, const uint64_t* beta_h_g2_mont, int* accepted);
+
 /* HomomorphicCommitment::multi_scalar_mul (commitment.rs:32-45) for ARBITRARY points: the verifier's 13-point
  * linearisation commitment and similar short combinations.  Host arithmetic (double-and-add on 64-bit limbs): at this
  * size a device launch would cost more than the sum.  scalars: 4 limbs each, Montgomery or canonical. */

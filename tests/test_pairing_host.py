@@ -101,6 +101,55 @@ def test_complete_verifier_accepts_honest_proofs_and_rejects_the_rest(cv, kind):
 
 
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_batch_verifier_folds_proofs_of_different_circuits_into_one_pairing_product(cv):
+    """zkt_verify_batch: proofs of two different circuits (own verifier keys, Merlin and Keccak transcripts on BN254) under
+    ONE structured reference string verify together; one bad proof, statement or trapdoor sinks the batch; a batch of one
+    agrees with zkt_verify."""
+    T = PR.Tower(cv)
+    tau = 0x1234567ABCDEF
+    H = PR.G2_GENERATORS[cv.name]
+    h, beta_h, wrong = g2_mont(cv, [H])[0], g2_mont(cv, [T.g2_mul(tau, H)])[0], g2_mont(cv, [T.g2_mul(tau + 1, H)])[0]
+    specs = [(150, 16, 77, 3, "merlin"), (90, 8, 78, 2, "ethereum" if cv.name == "bn254" else "merlin"), (150, 16, 79, 3, "merlin")]
+    made = []
+    srs = None
+    for gates, tbl, seed, n_public, kind in specs:
+        cs = P.synthetic_circuit(cv, gates, tbl, seed=seed, n_public=n_public)
+        n = cs.circuit_bound()
+        if srs is None:
+            srs = K.srs_mont(cv, tau, n + 8)            # the first circuit is the largest: one key for all
+        be = K.CBackend(cv, srs[:n + 8])
+        pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+        proof = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk, kind),
+                        field_elems(cv.fr.p, seed, P.NUM_BLINDERS)).serialize(cv)
+        made.append((vk, [cs.pi[k] for k in sorted(cs.pi)], proof, kind))
+
+    def item(vk, pis, raw, kind):
+        tr = z.Transcript(kind, "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8)
+        z.seed_transcript(tr, vk.n, vk.commits)
+        return (vk.n, K.points_to_mont(cv, [vk.commits[k] for k in z.PK_ORDER]), [vk.commits[k] is None for k in z.PK_ORDER],
+                K.fr_to_mont(cv, vk.pi_roots), K.fr_to_mont(cv, pis), raw, srs[0], tr)
+
+    def batch(entries, bh=beta_h):
+        return _lib.verify_batch(cv.name, [item(*e) for e in entries], h, bh)
+
+    assert batch(made)
+    assert batch(made[:1]) and batch(made[1:])
+    assert not batch(made, wrong)                                             # another trapdoor
+    for k in range(len(made)):
+        vk, pis, proof, kind = made[k]
+        bad = bytearray(proof)
+        bad[-40] ^= 1                                                         # a flipped evaluation in proof k
+        assert not batch(made[:k] + [(vk, pis, bytes(bad), kind)] + made[k + 1:])
+        assert not batch(made[:k] + [(vk, [(pis[0] + 1) % cv.fr.p] + pis[1:], proof, kind)] + made[k + 1:])
+    # swapping two proofs of the same shape between their statements is caught as well
+    assert not batch([made[0][:2] + made[2][2:], made[1], made[2][:2] + made[0][2:]])
+    with pytest.raises(_lib.ZktError):
+        _lib.verify_batch(cv.name, [], h, beta_h)
+    with pytest.raises(_lib.ZktError):                                        # malformed bytes fail the call
+        batch([made[0][:2] + (made[0][2][:-1],) + made[0][3:]])
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
 def test_pairing_smoke(cv):
     """Small enough for the AddressSanitizer run (tests/test_host_sanitize.py): one bilinearity identity and its negation."""
     T = PR.Tower(cv)

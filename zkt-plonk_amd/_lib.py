@@ -277,6 +277,40 @@ def verify(curve, n: int, vk_commits, vk_inf, pi_roots, pub_inputs, proof: bytes
     return bool(ok.value)
 
 
+def verify_batch(curve, items, h_g2, beta_h_g2) -> bool:
+    """zkt_verify_batch: `items` = [(n, vk_commits, vk_inf, pi_roots, pub_inputs, proof bytes, g_xy, seeded Transcript), ...];
+    True iff every proof verifies (one product of two pairings for the whole batch)."""
+    L = lib()
+    cid = curve_id(curve)
+    words = 8 if cid == CURVE_BN254 else 12
+    h = np.ascontiguousarray(h_g2, dtype=np.uint64).reshape(2 * words)
+    bh = np.ascontiguousarray(beta_h_g2, dtype=np.uint64).reshape(2 * words)
+    null = ctypes.POINTER(ctypes.c_uint64)()
+    k = len(items)
+    ins = (VerifyInputs * max(k, 1))()
+    trs = (ctypes.c_void_p * max(k, 1))()
+    keep = []
+    for i, (n, vk_commits, vk_inf, pi_roots, pub_inputs, proof, g_xy, transcript) in enumerate(items):
+        vk_commits = np.ascontiguousarray(vk_commits, dtype=np.uint64).reshape(10, words)
+        pi_roots = np.ascontiguousarray(pi_roots, dtype=np.uint64).reshape(-1, 4)
+        pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1, 4)
+        assert pi_roots.shape == pub_inputs.shape
+        g_xy = np.ascontiguousarray(g_xy, dtype=np.uint64).reshape(words)
+        inf = (ctypes.c_int * 10)(*[int(bool(x)) for x in vk_inf])
+        keep.append((vk_commits, pi_roots, pub_inputs, g_xy, inf, proof))
+        ins[i] = VerifyInputs(n, u64p(vk_commits), inf, u64p(pi_roots) if pi_roots.size else null,
+                              u64p(pub_inputs) if pub_inputs.size else null, pi_roots.shape[0], proof, len(proof), u64p(g_xy))
+        trs[i] = transcript.handle
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_verify_batch.argtypes = [ctypes.c_int, ctypes.POINTER(VerifyInputs), ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t,
+                                   P64, P64, ctypes.POINTER(ctypes.c_int)]
+    ok = ctypes.c_int(0)
+    rc = L.zkt_verify_batch(cid, ins, trs, k, u64p(h), u64p(bh), ctypes.byref(ok))
+    if rc:
+        raise ZktError(rc, "zkt_verify_batch")
+    return bool(ok.value)
+
+
 class ProveInputs(ctypes.Structure):
     _fields_ = [("a_evals", ctypes.POINTER(ctypes.c_uint64)), ("b_evals", ctypes.POINTER(ctypes.c_uint64)),
                 ("c_evals", ctypes.POINTER(ctypes.c_uint64)), ("n_rows", ctypes.c_size_t),

@@ -592,6 +592,83 @@ static int verify_t(int curve_id, const zkt_verify_inputs* in, zkt_transcript* t
     return ZKT_OK;
 }
 
+// k proofs under the SAME structured reference string (h, beta h; the circuits and verifier keys may differ), ONE product of
+// two pairings for all of them: every proof contributes its two folded openings (L_2i, W_2i), (L_2i+1, W_2i+1), and
+//     e(sum_j rho_j L_j, h) e(-sum_j rho_j W_j, beta h) == 1,   rho_0 = 1, rho_j = low 128 bits of Keccak-256(seed || j),
+// seed = Keccak-256 over the curve, k, every (L, W) and (h, beta h).  All 2k checks hold => the product is one; if any
+// fails, the product is one for at most a 2^-128 fraction of the seeds.  A rejected batch says nothing about WHICH proof
+// is bad: the caller falls back to zkt_verify per proof.  The reference has no such entry (its PC::check folds the two
+// openings of one proof only, proof.rs:441,479); this is the service-side extension SURVEY.md 8f.4 asks for.
+template <class C>
+static int verify_batch_t(int curve_id, const zkt_verify_inputs* ins, zkt_transcript* const* trs, size_t k, const uint64_t* h,
+                          const uint64_t* beta_h, int* accepted) {
+    using Q = typename C::Fq;
+    using R = typename C::Fr;
+    using HX = hostec::HX<Q>;
+    constexpr int L64 = Q::N / 2;
+    const size_t pair_words = (size_t)8 * L64;               // L1, W1, L2, W2 of one proof
+    std::vector<uint64_t> pairs(k * pair_words);
+    for (size_t i = 0; i < k; ++i) {
+        if (!trs[i]) return ZKT_ERR_INVALID_ARGUMENT;
+        int inf[4];
+        int rc = zkt_verify_prepare(curve_id, &ins[i], trs[i], pairs.data() + i * pair_words, inf);
+        if (rc) return rc;
+    }
+    uint8_t seed[32];
+    {
+        std::vector<uint8_t> buf(4 + 8 + pairs.size() * 8 + (size_t)8 * L64 * 8);
+        const uint32_t cid = (uint32_t)curve_id;
+        const uint64_t kk = (uint64_t)k;
+        size_t at = 0;
+        memcpy(buf.data() + at, &cid, 4); at += 4;
+        memcpy(buf.data() + at, &kk, 8); at += 8;
+        memcpy(buf.data() + at, pairs.data(), pairs.size() * 8); at += pairs.size() * 8;
+        memcpy(buf.data() + at, h, (size_t)4 * L64 * 8); at += (size_t)4 * L64 * 8;
+        memcpy(buf.data() + at, beta_h, (size_t)4 * L64 * 8);
+        keccak256(buf.data(), buf.size(), seed);
+    }
+    const size_t m = 2 * k;
+    std::vector<Fe<R>> rho(m);
+    std::vector<HX> lp(m), wp(m);
+    for (size_t j = 0; j < m; ++j) {
+        if (j == 0) {
+            rho[j] = fe_one<R>();
+        } else {
+            uint8_t msg[40], dg[32];
+            const uint64_t jj = (uint64_t)j;
+            memcpy(msg, seed, 32);
+            memcpy(msg + 32, &jj, 8);
+            keccak256(msg, sizeof msg, dg);
+            Fe<R> r = fe_zero<R>();
+            memcpy(r.v, dg, 16);                       // 128 bits: below both scalar moduli
+            rho[j] = fe_to_mont<R>(r);
+        }
+        auto point = [&](size_t idx) {
+            Affine<Q> a;
+            memcpy(a.x.v, pairs.data() + idx * 2 * L64, L64 * 8);
+            memcpy(a.y.v, pairs.data() + idx * 2 * L64 + L64, L64 * 8);
+            return hostec::hx_from<Q>(xyzz_from_affine<Q>(a));
+        };
+        lp[j] = point(2 * j);          // pairs are laid out L, W, L, W, ...
+        wp[j] = point(2 * j + 1);
+    }
+    const Affine<Q> lc = xyzz_to_affine_host<Q>(hostec::hx_to<Q>(msm_wnaf<C>(lp.data(), rho.data(), (int)m)));
+    Affine<Q> wc = xyzz_to_affine_host<Q>(hostec::hx_to<Q>(msm_wnaf<C>(wp.data(), rho.data(), (int)m)));
+    if (!aff_is_inf<Q>(wc)) wc.y = fe_neg<Q>(wc.y);
+    uint64_t g1[2 * 12], g2[2 * 4 * 6];
+    memcpy(g1, lc.x.v, L64 * 8);
+    memcpy(g1 + L64, lc.y.v, L64 * 8);
+    memcpy(g1 + 2 * L64, wc.x.v, L64 * 8);
+    memcpy(g1 + 3 * L64, wc.y.v, L64 * 8);
+    memcpy(g2, h, 4 * L64 * 8);
+    memcpy(g2 + 4 * L64, beta_h, 4 * L64 * 8);
+    int one = 0;
+    int rc = pairing_check_t<C>(g1, g2, 2, &one);
+    if (rc) return rc;
+    *accepted = one ? 1 : 0;
+    return ZKT_OK;
+}
+
 // ---- the G2 half of the test / bench SRS (zkt_srs_generate is the G1 half): h = the G2 generator of ark-bn254 /
 // ---- ark-bls12-381 (published constants), beta h = tau h by double-and-add on the twist (one-time, host) ----------
 template <class C>
@@ -669,6 +746,17 @@ extern "C" int zkt_verify(int curve_id, const zkt_verify_inputs* in, zkt_transcr
     if (!in || !transcript || !h_g2_mont || !beta_h_g2_mont || !accepted) return ZKT_ERR_INVALID_ARGUMENT;
     if (curve_id == ZKT_CURVE_BN254) return verify_t<Bn254Curve>(curve_id, in, transcript, h_g2_mont, beta_h_g2_mont, accepted);
     if (curve_id == ZKT_CURVE_BLS12_381) return verify_t<Bls381Curve>(curve_id, in, transcript, h_g2_mont, beta_h_g2_mont, accepted);
+    return ZKT_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int zkt_verify_batch(int curve_id, const zkt_verify_inputs* ins, zkt_transcript* const* transcripts, size_t count,
+                                const uint64_t* h_g2_mont, const uint64_t* beta_h_g2_mont, int* accepted) {
+    if (!ins || !transcripts || count == 0 || count > (1u << 20) || !h_g2_mont || !beta_h_g2_mont || !accepted)
+        return ZKT_ERR_INVALID_ARGUMENT;
+    if (curve_id == ZKT_CURVE_BN254)
+        return verify_batch_t<Bn254Curve>(curve_id, ins, transcripts, count, h_g2_mont, beta_h_g2_mont, accepted);
+    if (curve_id == ZKT_CURVE_BLS12_381)
+        return verify_batch_t<Bls381Curve>(curve_id, ins, transcripts, count, h_g2_mont, beta_h_g2_mont, accepted);
     return ZKT_ERR_INVALID_ARGUMENT;
 }
 
