@@ -73,6 +73,8 @@ extern "C" {
                            out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
     pub fn zkt_verify(curve_id: c_int, inputs: *const ZktVerifyInputs, transcript: *mut c_void, h_g2_mont: *const u64,
                       beta_h_g2_mont: *const u64, accepted: *mut c_int) -> c_int;
+    pub fn zkt_verify_batch(curve_id: c_int, inputs: *const ZktVerifyInputs, transcripts: *const *mut c_void, count: usize,
+                            h_g2_mont: *const u64, beta_h_g2_mont: *const u64, accepted: *mut c_int) -> c_int;
     pub fn zkt_poseidon_load(ctx: *mut ZktCtx, params: *const ZktPoseidonParams, out: *mut *mut c_void) -> c_int;
     pub fn zkt_poseidon_free(ctx: *mut ZktCtx, params: *mut c_void);
     pub fn zkt_poseidon_hash_batch_dev(ctx: *mut ZktCtx, params: *const c_void, d_inputs: *const c_void, batch: usize,
