@@ -34,6 +34,21 @@ def test_srs_generate_matches_oracle(cv, ctxs, golden):
     assert K.points_from_mont(cv, got[:4]) == [unhex_point(p) for p in golden[cv.name]["srs_first"]]
 
 
+def test_msm_reproduces_the_public_bn254_doubling_vector(ctxs):
+    """EIP-196's bn256Add(G, G) -- a known answer that comes from neither the reference nor this repository -- through
+    the device MSM: with tau = 1 every SRS power is G, so <(1, 1), SRS> = <(2), SRS> = 2 G."""
+    from test_oracle_primitives import BN254_2G
+    cv = F.BN254
+    ctx = ctxs[cv.name]
+    ctx.srs_generate(1, 64)
+    assert K.points_from_mont(cv, ctx.srs_download(0, 2)) == [C.generator(cv)] * 2
+    for sc in ([2], [1, 1], [0, 2, 0], [cv.fr.p - 1, 3], [1] * 2 + [0] * 40):
+        out, inf = ctx.msm(K.fr_to_mont(cv, sc))
+        assert _pt(cv, out, inf) == BN254_2G, sc
+        out, inf = ctx.msm(K.ints_to_limbs(sc, 4), montgomery=False)
+        assert _pt(cv, out, inf) == BN254_2G, sc
+
+
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
 def test_msm_golden_vectors(cv, ctxs, golden):
     ctx = ctxs[cv.name]

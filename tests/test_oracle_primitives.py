@@ -44,6 +44,30 @@ def test_keccak_against_hashlib():
         assert T.sha3_256(m) == hashlib.sha3_256(m).digest()
 
 
+# Public known answers that come from neither the reference nor this repository: legacy Keccak-256 of "" and "abc"
+# (the Ethereum yellow paper's hash; hashlib has no legacy padding) and G + G on alt_bn128 (EIP-196's bn256Add vector).
+KECCAK_EMPTY = "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+KECCAK_ABC = "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+BN254_2G = (0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3,
+            0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4)
+
+
+def test_public_known_answers_keccak_and_bn254_doubling():
+    assert T.keccak256(b"").hex() == KECCAK_EMPTY
+    assert T.keccak256(b"abc").hex() == KECCAK_ABC
+    G = C.generator(F.BN254)
+    assert C.add(F.BN254, G, G) == BN254_2G == C.scalar_mul(F.BN254, 2, G) == C.double(F.BN254, G)
+    # ... and the product's own host arithmetic (zkt_g1_sum_host, zkt_g1_msm_host, the Keccak transcript's hash)
+    import numpy as np
+    from oracle import coracle as K
+    from zkt_plonk_amd import _lib
+    g = K.points_to_mont(F.BN254, [G, G])
+    out, inf = _lib.g1_sum_host("bn254", g)
+    assert not inf and K.points_from_mont(F.BN254, out.reshape(1, -1))[0] == BN254_2G
+    out, inf = _lib.g1_msm_host("bn254", g[:1], K.fr_to_mont(F.BN254, [2]))
+    assert not inf and K.points_from_mont(F.BN254, np.asarray(out).reshape(1, -1))[0] == BN254_2G
+
+
 def test_merlin_conformance_vector():
     # merlin's published cross-implementation vector ("test protocol" / "some label" / "some data")
     t = T.Merlin(b"test protocol")
