@@ -3,4 +3,4 @@ import json,sys
 d=json.loads(open(\"gpurun_out/r03_q_$tag.json\").read().strip().splitlines()[-1])
 l=d[\"latency\"]; k=d[\"kernels\"]
 print(\"$tag\", d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"avg_launch_ms\"], d[\"int_alu\"][\"msm_main_stream_avg_ms\"], d[\"int_alu\"][\"msm_tail_avg_ms\"], k[\"ntt_2^20\"][\"avg_ms\"], k[\"ntt_2^22\"][\"avg_ms\"], k[\"quotient\"][\"avg_ms\"], l[\"cold_single_proof_ms\"], l[\"unchained_single_proof_ms\"])
-"; }; for i in 1 2; do run new$i X=1 && run prev$i ZKT_LIB_PATH=$PWD/_ab/libzkt_r03g.so; done; }
+"; }; for i in 1 2; do run new$i X=1 && run prev$i ZKT_LIB_PATH=$PWD/_ab/libzkt_r03h.so; done; }
