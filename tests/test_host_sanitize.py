@@ -20,6 +20,7 @@ def test_host_entry_points_under_asan_and_ubsan():
     env = dict(os.environ, ZKT_LIB_PATH=lib, LD_PRELOAD=rt, ZKT_SKIP_SLOW_ORACLE="1",
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
     tests = ["tests/test_field_host.py", "tests/test_transcript_host.py", "tests/test_cabi.py", "tests/test_keyfile_host.py", "tests/test_verify_host.py", "tests/test_pairing_host.py::test_pairing_smoke",
+             "tests/test_pairing_host.py::test_batch_verifier_folds_proofs_of_different_circuits_into_one_pairing_product",
              "tests/test_parallel_gloo.py::test_g1_sum_host_matches_oracle",
              "tests/test_parallel_gloo.py::test_shard_range_covers_everything"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + tests, cwd=ROOT, env=env,
