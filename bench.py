@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- proofs/sec of the MI355X prover hot path on a synthetic withdraw-shaped circuit.
+"""bench.py -- proofs/sec of the MI355X prover hot path on the reference's withdraw circuit.
 
 A "step" is one full pass of proof_system::prove (plonk-core/src/proof_system/prove.rs:59-470) over one
 batch of synthetic witness rows already resident in HBM: iNTT(n) of every witness polynomial, their
 coset NTT(4n), the fused quotient pass, two grand products, the 12-13 KZG commitments (MSMs of ~n points),
-the 12 evaluations and the two openings, with Fiat-Shamir (Merlin) on the host.  Default workload:
-BASELINE.json configs[3] shape -- BN254, n = 2^20 rows, TABLE_SIZE = 1024, 7 public inputs.
+the 12 evaluations and the two openings, with Fiat-Shamir (Merlin) on the host.  Default workload
+(`--workload withdraw`): BASELINE.json configs[3] -- WithdrawCircuit<Fr, u64, _, Bn254x5, INPUTS = 8, HEIGHT = 64>
+(circuits/src/withdraw.rs:57-150: 538 Poseidon gadgets of 1888 gates, Merkle paths, identifier lookups, 64-bit range and
+balance rows; 1 019 498 gates -> n = 2^20, TABLE_SIZE = 1024, 12 public inputs), laid out by tools/withdraw_workload.py
+for a synthetic wallet.  Its witness is made where the prover reads it: the host computes the ~4 600 variables that are
+not outputs of Poseidon gates (note data, paths, selects; the hash VALUES natively, as bin/src/main.rs:248-271 does) and
+the device fills the other 1 015 744 (k_poseidon_gadget, `witness` in the JSON line; outside the timed region, like
+`circuit.synthesize` is outside proof_system::prove).  `--workload synthetic` is the r01-r03 workload (random mul / add /
+linear rows, a lookup every 16th, 7 public inputs).
 
 Headline (`value`): steady state of a proving service with a queue -- two DISTINCT witnesses of the circuit
 alternate, each proof announces its successor (zkt_prove_set_next), witnesses resident in HBM, the lookup
@@ -136,6 +143,106 @@ def synthetic_circuit(fld, log_n, table_size=1024, n_public=7, seed=0x5EED, valu
     return dict(n=n, gates=gates, a=a, b=b, c=c, sel=sel, table=table, pi=pi)
 
 
+WITHDRAW_SHAPES = {14: (4, 1, 7), 18: (4, 3, 48), 19: (5, 4, 64), 20: (5, 8, 64), 22: (5, 32, 64)}   # width, INPUTS, HEIGHT
+
+
+def synthetic_workload(z, torch, ctx, dev, fld, args, log_n):
+    """ONE circuit, TWO witnesses (free wire values, looked-up entries and public inputs all differ); wires resident in HBM."""
+    import random
+    circs = [synthetic_circuit(fld, log_n, value_seed=1 + k) for k in range(2)]
+    assert circs[0]["sel"] == circs[1]["sel"] and circs[0]["table"] == circs[1]["table"] and circs[0]["pi"] != circs[1]["pi"]
+    # proof_system::setup on the device (setup.rs:42-166): selector / sigma / table-mask evaluations -> ProverKey,
+    # ExtendedProverKey and the ten VerifierKey commitments that seed the transcript
+    evals = {name: fr_to_mont_gpu(ctx, fld, circs[0]["sel"][name]) for name in z.PK_ORDER}
+    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    gates = circs[0]["gates"]
+    table = fr_to_mont_gpu(ctx, fld, circs[0]["table"])
+    rnd = random.Random(99)
+    host_w, keep, preps, pis = [], [], [], []
+    for circ in circs:
+        hw = [fr_to_mont_gpu(ctx, fld, circ[k][:gates]) for k in "abc"]
+        dw = [torch.from_numpy(x.view(np.int64)).to(dev) for x in hw]
+        pi_pos = sorted(circ["pi"])
+        pi_vals = fr_to_mont_gpu(ctx, fld, [circ["pi"][k] for k in pi_pos])
+        blinders = fr_to_mont_gpu(ctx, fld, [rnd.randrange(fld["r"]) for _ in range(z.NUM_BLINDERS)])
+        host_w.append(hw); keep.append(dw); pis.append((pi_pos, pi_vals, blinders))
+        preps.append(ctx.prepare_dev(dw[0].data_ptr(), dw[1].data_ptr(), dw[2].data_ptr(), gates, table, pi_pos, pi_vals,
+                                     blinders))
+    return dict(evals=evals, commits=commits, gates=gates, table=table, host_w=host_w, preps=preps, pis=pis,
+                pi_map0=dict(circs[0]["pi"]), keep=keep, witness=None,
+                describe="full prove, synthetic withdraw-shaped circuit, %s, n=2^%d, TABLE_SIZE=1024, 7 public inputs"
+                         % (args.curve, log_n))
+
+
+def withdraw_workload(z, torch, ctx, dev, fld, args, log_n):
+    """The reference's WithdrawCircuit filling 2^log_n rows, ONE circuit and TWO wallets / withdrawals.  Per witness the
+    host uploads the variables that are not Poseidon gate outputs, the device makes the rest (PoseidonGadget.fill); the
+    prover is handed the composer's own layout: the variable map and the three wire -> variable index vectors, all in HBM
+    (prove.rs:49-55 wire_evals runs on the device inside the timed proof)."""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import withdraw_workload as WW
+    p = fld["r"]
+    width, inputs, height = WITHDRAW_SHAPES[log_n]
+    hs = WW.reference_hasher(p, width) if args.curve == "bn254" else WW.synthetic_hasher(p, width)
+    insts = [WW.make_instance(hs, inputs, height, seed=0x5EED + k) for k in range(2)]
+    lays = [WW.layout(hs, inst) for inst in insts]
+    L0 = lays[0]
+    assert lays[1].q == L0.q and lays[1].w == L0.w and sorted(lays[1].pi) == sorted(L0.pi) and lays[1].values != L0.values
+    gates, n_vars = L0.n_gates, len(L0.values)
+    assert gates <= (1 << log_n)
+    sel = WW.setup_vectors(L0, log_n, fld["gen"])
+    evals = {name: fr_to_mont_gpu(ctx, fld, sel[name]) for name in z.PK_ORDER}
+    del sel
+    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    table = fr_to_mont_gpu(ctx, fld, insts[0]["ident_set"])
+    to_mont = lambda vals: fr_to_mont_gpu(ctx, fld, vals)
+    gadget = z.PoseidonGadget(ctx, hs.width, hs.half_full, hs.partial, to_mont(hs.rc), to_mont([x for row in hs.mds for x in row]),
+                              to_mont([hs.tag])[0])
+    assert gadget.vars_per_hash == hs.per_hash
+    for base, ins in L0.hash_calls:
+        gadget.hash(base, ins)
+    gadget.stage()
+    idx = [np.asarray(w, dtype=np.uint32) for w in L0.w]
+    d_idx = [torch.from_numpy(x.view(np.int32)).to(dev) for x in idx]
+    rnd = random.Random(99)
+    host_w, keep, preps, pis, dev_ms = [], [], [], [], []
+    for lay in lays:
+        host_vals = to_mont(lay.values)                        # zeros where the device writes
+        d_vars = torch.from_numpy(host_vals.view(np.int64)).to(dev)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(5):                                     # the same values every time: min of 5
+            t = time.perf_counter()
+            gadget.fill(d_vars.data_ptr(), n_vars, check=False)
+            ctx.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t))
+        gadget.fill(d_vars.data_ptr(), n_vars, check=True)
+        dev_ms.append(min(ts))
+        # wire evaluations on the host as well (the cold leg, the CPU baseline and the sharded leg take a, b, c)
+        full = np.concatenate([d_vars.cpu().numpy().view(np.uint64).reshape(n_vars, 4), np.zeros((1, 4), np.uint64)])
+        hw = [full[np.where(x == WW.ZERO, n_vars, x)] for x in idx]
+        pi_pos = sorted(lay.pi)
+        pi_vals = to_mont([lay.pi[k] for k in pi_pos])
+        blinders = to_mont([rnd.randrange(p) for _ in range(z.NUM_BLINDERS)])
+        host_w.append(hw); keep.append(d_vars); pis.append((pi_pos, pi_vals, blinders))
+        preps.append(ctx.prepare_vars_dev(d_vars.data_ptr(), n_vars, d_idx[0].data_ptr(), d_idx[1].data_ptr(), d_idx[2].data_ptr(),
+                                          gates, table, pi_pos, pi_vals, blinders))
+    n_host = n_vars - len(L0.hash_calls) * hs.per_hash
+    witness = {"hashes": len(L0.hash_calls), "vars_per_hash": hs.per_hash, "variables": n_vars, "host_made_variables": n_host,
+               "device_made_variables": n_vars - n_host, "device_ms": round(min(dev_ms), 3),
+               "launches": len(gadget._staged),
+               "is": "k_poseidon_gadget: every variable the PlonkSpecRef gadget allocates (x^2, x^4, x^5 per s-box, the W^2 "
+                     "running MDS sums per round) for all the circuit's hashes, written into the variable map in HBM; one "
+                     "thread per hash, so a single proof's %d hashes are latency-bound (a proving service batches the hashes "
+                     "of its queue); wall clock incl. launch, min of 5; outside the timed region" % len(L0.hash_calls)}
+    return dict(evals=evals, commits=commits, gates=gates, table=table, host_w=host_w, preps=preps, pis=pis,
+                pi_map0=dict(L0.pi), keep=(keep, d_idx, gadget), witness=witness, oracle_twin=(hs, insts[0]),
+                describe="full prove, WithdrawCircuit INPUTS=%d HEIGHT=%d Poseidon x%d (%d gates, %d Poseidon gadgets), %s, n=2^%d, "
+                         "TABLE_SIZE=1024, %d public inputs" % (inputs, height, width, gates, len(L0.hash_calls), args.curve, log_n,
+                                                                len(L0.pi)))
+
+
 def launch_workers(args, argv):
     """`--gpus N` without a torchrun environment: start the N workers ourselves, as child processes, before this
     process has touched a GPU (it never does: no torch / HIP call happens on this path)."""
@@ -158,6 +265,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--curve", default="bn254", choices=sorted(FIELDS))
+    ap.add_argument("--workload", default="withdraw", choices=["withdraw", "synthetic"],
+                    help="withdraw: the reference's WithdrawCircuit sized to fill 2^log_n rows (log-n 14, 18, 19, 20, 22), "
+                         "Poseidon witness made on the device; synthetic: random withdraw-shaped rows of any size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the cold / unchained single-proof legs")
     ap.add_argument("--shard", default="both", choices=["proofs", "proof", "both"],
@@ -198,16 +308,18 @@ def main():
     tau = 0x5EED5EED1234567890ABCDEF % fld["r"]
     ctx.srs_generate(tau, n + 8)
 
-    # ONE circuit, TWO witnesses (free wire values, looked-up entries and public inputs all differ)
-    circs = [synthetic_circuit(fld, log_n, value_seed=1 + k) for k in range(2)]
-    assert circs[0]["sel"] == circs[1]["sel"] and circs[0]["table"] == circs[1]["table"] and circs[0]["pi"] != circs[1]["pi"]
-    # proof_system::setup on the device (setup.rs:42-166): selector / sigma / table-mask evaluations -> ProverKey,
-    # ExtendedProverKey and the ten VerifierKey commitments that seed the transcript
-    evals = {name: fr_to_mont_gpu(ctx, fld, circs[0]["sel"][name]) for name in z.PK_ORDER}
-    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if args.workload == "withdraw" and log_n not in WITHDRAW_SHAPES:
+        sys.stderr.write("bench.py: no withdraw shape fills n = 2^%d (have %s); using --workload synthetic\n"
+                         % (log_n, sorted(WITHDRAW_SHAPES)))
+        args.workload = "synthetic"
+    build = withdraw_workload if args.workload == "withdraw" else synthetic_workload
+    wl = build(z, torch, ctx, dev, fld, args, log_n)
+    evals, gates, table, host_w, preps, pis, pi_map0 = (wl[k] for k in ("evals", "gates", "table", "host_w", "preps", "pis", "pi_map0"))
+    commits = wl["commits"]
     evals_keep = evals if (world > 1 and args.shard != "proofs") else None
     if not want_cpu:
+        wl["evals"] = None
         del evals
     L = fld["fq_limbs"]
     rinv_q = pow(1 << (64 * L), -1, fld["q"])
@@ -220,22 +332,6 @@ def main():
             x = sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv_q % fld["q"]
             y = sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv_q % fld["q"]
             vk[name] = (x, y)
-    gates = circs[0]["gates"]
-    table = fr_to_mont_gpu(ctx, fld, circs[0]["table"])
-    import random
-    rnd = random.Random(99)
-    host_w, dev_w, preps, pis = [], [], [], []
-    for circ in circs:
-        hw = [fr_to_mont_gpu(ctx, fld, circ[k][:gates]) for k in "abc"]
-        dw = [torch.from_numpy(x.view(np.int64)).to(dev) for x in hw]
-        pi_pos = sorted(circ["pi"])
-        pi_vals = fr_to_mont_gpu(ctx, fld, [circ["pi"][k] for k in pi_pos])
-        blinders = fr_to_mont_gpu(ctx, fld, [rnd.randrange(fld["r"]) for _ in range(z.NUM_BLINDERS)])
-        host_w.append(hw); dev_w.append(dw); pis.append((pi_pos, pi_vals, blinders))
-        preps.append(ctx.prepare_dev(dw[0].data_ptr(), dw[1].data_ptr(), dw[2].data_ptr(), gates, table, pi_pos, pi_vals,
-                                     blinders))
-    pi_map0 = dict(circs[0]["pi"])
-    del circs
     setup_s = time.time() - t0
 
     # Timed regime: the two witnesses alternate; every proof announces the next one (zkt_prove_set_next), as a proving
@@ -438,8 +534,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)",
         "data": "synthetic",
-        "config": {"workload": "full prove, synthetic withdraw-shaped circuit, %s, n=2^%d, TABLE_SIZE=1024, 7 public inputs"
-                               % (args.curve, log_n), "parallelism": "proofs sharded across %d GPU(s)" % world,
+        "config": {"workload": wl["describe"], "parallelism": "proofs sharded across %d GPU(s)" % world,
                    "chained": bool(chain), "distinct_witnesses": 2, "witness_on_device": True, "table_cached": True,
                    "proof_bytes": len(proof), "setup_s": round(setup_s, 1)},
         "roofline": roofline, "int_alu": int_alu, "kernels": ntt,
@@ -448,6 +543,9 @@ def main():
                             "chained proofs with every scope on, outside the timed region (stream time, first to last "
                             "launch of the scope; round4 / round5 contain the early round1 / round2 of the next proof)" % prof_steps,
     }
+    if wl.get("witness") is not None:
+        out["witness"] = wl["witness"]
+        out["poseidon_witness_ms"] = wl["witness"]["device_ms"]
     if latency is not None:
         out["latency"] = latency
     if verify is not None:
@@ -473,7 +571,8 @@ def main():
     if want_cpu:
         pi_pos, pi_vals, blinders = pis[0]
         gpu_proof = ctx.prove_prepared(preps[0], transcript())
-        out["cpu_baseline"] = cpu_baseline(ctx, args.curve, log_n, evals, host_w[0], table, pi_map0, blinders, vk, gpu_proof)
+        out["cpu_baseline"] = cpu_baseline(ctx, args.curve, log_n, evals, host_w[0], table, pi_map0, blinders, vk, gpu_proof,
+                                           wl.get("oracle_twin"))
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
@@ -635,7 +734,7 @@ def pmc_valu_busy(kernel, curve, log_n):
     return round(best[1], 4), "profiles/" + best[2]
 
 
-def cpu_baseline(ctx, curve, log_n, evals, wires, table, pi, blinders, vk_pts, gpu_proof):
+def cpu_baseline(ctx, curve, log_n, evals, wires, table, pi, blinders, vk_pts, gpu_proof, oracle_twin=None):
     """ONE full proof of the same workload by the CPU oracle (oracle/fastplonk.py: the array twin of the restated
     prove.rs:59-470, every O(n) loop in oracle/coracle.cpp -- a port of ark-poly's radix-2 FFT, ark-ec's Pippenger
     and the prover's own loops, OpenMP over the host cores), timed, on the same SRS / witness / blinders; its bytes
@@ -651,9 +750,22 @@ def cpu_baseline(ctx, curve, log_n, evals, wires, table, pi, blinders, vk_pts, g
     t = time.perf_counter()
     cpu_proof = FP.prove(cv, srs, keys, wires[0], wires[1], wires[2], table, pi, P.new_seeded_transcript(cv, vk), bl)
     dt = time.perf_counter() - t
-    return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": K.num_threads(), "kind": "port",
-            "sample": "1 full proof (n=2^%d, same SRS / witness / blinders as the GPU proof) in %.2f s" % (log_n, dt),
-            "proof_bytes_equal_gpu": cpu_proof == gpu_proof}
+    res = {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": K.num_threads(), "kind": "port",
+           "sample": "1 full proof (n=2^%d, same SRS / witness / blinders as the GPU proof) in %.2f s" % (log_n, dt),
+           "proof_bytes_equal_gpu": cpu_proof == gpu_proof}
+    if oracle_twin is not None:
+        # the checker's own synthesis of the same withdrawal (oracle/composer.py: the reference's composer restated gate by
+        # gate): its wire values -- Poseidon variables included -- must be the ones the device made (untimed)
+        from oracle import composer as OC
+        hs, inst = oracle_twin
+        prm = OC.PoseidonParams(cv.fr.p, hs.width, hs.half_full, hs.partial, hs.rc, hs.mds, hs.tag)
+        cs = OC.Composer(cv, inst["ident_set"], 1024)
+        OC.withdraw_synthesize(cs, prm, inst["secrets"], inst["identifiers"], inst["amounts"], inst["poes"], inst["root"],
+                               inst["new_secret"], inst["new_identifier"], inst["withdraw_amount"])
+        a, b, c = cs.wire_evals(cs.n_gates)
+        res["witness_equals_oracle_composer"] = bool(
+            cs.check_satisfied() and all(np.array_equal(K.fr_to_mont(cv, x), np.asarray(w)) for x, w in zip((a, b, c), wires)))
+    return res
 
 
 if __name__ == "__main__":

@@ -274,12 +274,13 @@ int zkt_prove_set_next(zkt_ctx* ctx, const zkt_prove_inputs* next);
 int zkt_prove_with(zkt_ctx* ctx, const zkt_prove_inputs* in, const zkt_transcript_vtable* transcript,
                    uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 
-/* ---- Witness synthesis for Poseidon-heavy circuits as a batched field kernel ---------------------
- * The permutation of plonk-hashing/src/hasher/poseidon/spec.rs (rounds :18-111, schedule :267-316, input layout
+/* ---- Witness synthesis for Poseidon-heavy circuits as batched field kernels ----------------------
+ * (1) The permutation of plonk-hashing/src/hasher/poseidon/spec.rs (rounds :18-111, schedule :267-316, input layout
  * :239-265: state[0] = domain_tag, the inputs follow, output = state[1]) for `batch` independent hashes, one thread per
- * hash; out_states (optional) receives every round's state, batch x (rounds + 1) x width scalars, i.e. the values a
- * composer assigns to the variables of its Poseidon gates.  Constants are the caller's PoseidonConstants (the
- * reference generates them at run time, constants.rs:27).  Everything in Montgomery limbs; host pointers. */
+ * hash: what NativePlonkSpecRef computes.  out_states (optional) receives every round's state, batch x (rounds + 1) x
+ * width scalars -- ROUND STATES ONLY: they are not the variables of the in-circuit gadget (that is (2) below).
+ * Constants are the caller's PoseidonConstants (the reference generates them at run time, constants.rs:27, or parses the
+ * BN254 tables of gadgets/src/poseidon).  Everything in Montgomery limbs; host pointers. */
 typedef struct {
     int width;                       /* 2 .. 8 */
     int half_full_rounds;            /* full rounds before and after the partial ones */
@@ -292,15 +293,47 @@ int zkt_poseidon_hash_batch(zkt_ctx* ctx, const zkt_poseidon_params* params, con
                             uint64_t* out_hashes, uint64_t* out_states);
 /* The same with everything resident in HBM: zkt_poseidon_load uploads the parameters once (as the kernel's own 29-bit
  * limbs), zkt_poseidon_hash_batch_dev takes DEVICE pointers, allocates nothing and enqueues on the context's stream
- * without synchronising.  d_out_states (optional, batch x (rounds + 1) x width scalars, arkworks Montgomery form) is laid
- * out as a variable map: it can be handed straight to zkt_prove_inputs.variables with wires_on_device = 1, w_l / w_r /
- * w_o indexing into it, so a Poseidon-heavy witness never crosses PCIe.  half_full_rounds >= 1 and partial_rounds >= 1
- * (output_hash, spec.rs:267-316, always runs one of each before its loops). */
+ * without synchronising.  d_out_states: optional, batch x (rounds + 1) x width scalars (round states, see above).
+ * half_full_rounds >= 1 and partial_rounds >= 1 (output_hash, spec.rs:267-316, always runs one of each before its loops). */
 typedef struct zkt_poseidon zkt_poseidon;
 int zkt_poseidon_load(zkt_ctx* ctx, const zkt_poseidon_params* params, zkt_poseidon** out);
 void zkt_poseidon_free(zkt_ctx* ctx, zkt_poseidon* params);
 int zkt_poseidon_hash_batch_dev(zkt_ctx* ctx, const zkt_poseidon* params, const void* d_inputs, size_t batch, int arity,
                                 void* d_out_hashes, void* d_out_states);
+
+/* (2) The WITNESS of the in-circuit gadget PoseidonRef<ConstraintSystem, PlonkSpecRef, _, WIDTH>::hash (spec.rs:174-219,
+ * 343-375).  While the reference's composer synthesises one hash it assigns a fresh variable per gate
+ * (constraint_system/arithmetic.rs:19,79; variable.rs:117-126): power_of_5 is three mul_gates (x^2, x^4, x^5;
+ * spec.rs:107-111), every term of product_mds an add_gate (the W^2 running sums, j outer, i inner; spec.rs:73-88);
+ * add_constant / mul_constant allocate nothing (lazy LTVariable transforms, variable.rs:77-86).  That is
+ *     zkt_poseidon_gadget_vars_per_hash = 2 half_full (3 W + W^2) + partial (3 + W^2)      (804 / 1288 / 1888 for x3 / x4 / x5)
+ * variables per hash, consecutive in VariableMap::values.  This entry point computes exactly those values for `batch`
+ * independent hashes and writes them, in allocation order, into the variable map the prover gathers its wires from
+ * (zkt_prove_inputs.variables with wires_on_device = 1): hash h fills d_variables[base .. base + vars_per_hash) with
+ * base = d_trace_base[h], or trace_base0 + h * vars_per_hash when d_trace_base is NULL.  The hash value (elements[1] after
+ * the last round, spec.rs:315) is the variable at base + vars_per_hash - 1 - (W - 2) W; d_out_hashes (optional) receives
+ * it as well.  Inputs are plain variables (coeff 1, offset 0: every call site of circuits/src/withdraw.rs and
+ * plonk-hashing/src/merkle/binary.rs): their VALUES in d_inputs (batch x arity), or their INDICES into d_variables in
+ * d_input_vars (ZKT_VARIABLE_ZERO = Variable::Zero) -- exactly one of the two.  Hashes of one launch are independent:
+ * an input may not be a variable the same launch writes.  Device pointers, no allocation, no synchronisation; a trace
+ * base or input index outside [0, n_vars) makes the kernel skip that hash and raise a flag that
+ * zkt_poseidon_gadget_check (which synchronises the stream) turns into ZKT_ERR_INVALID_ARGUMENT.
+ * "Parity unpinned": the reference holds no known answer for the gadget; tests compare with the oracle's gate-by-gate
+ * restatement of the composer. */
+typedef struct {
+    size_t batch;
+    int arity;                      /* inputs per hash, <= width - 1 */
+    const void* d_inputs;           /* batch x arity scalars, or NULL */
+    const uint32_t* d_input_vars;   /* batch x arity variable indices, or NULL */
+    void* d_variables;              /* VariableMap::values, n_vars scalars */
+    size_t n_vars;
+    const uint32_t* d_trace_base;   /* per hash, or NULL */
+    size_t trace_base0;
+    void* d_out_hashes;             /* optional: batch scalars */
+} zkt_poseidon_gadget_args;
+size_t zkt_poseidon_gadget_vars_per_hash(const zkt_poseidon* params);
+int zkt_poseidon_gadget_witness_dev(zkt_ctx* ctx, const zkt_poseidon* params, const zkt_poseidon_gadget_args* args);
+int zkt_poseidon_gadget_check(zkt_ctx* ctx, const zkt_poseidon* params);
 
 /* ---- Verifier (proof_system/proof.rs:285-503): zkt_verify_prepare = everything but the pairings,
  * ---- zkt_pairing_product_is_one = the pairings, zkt_verify = both ------------------------------------------------

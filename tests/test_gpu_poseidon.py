@@ -123,60 +123,150 @@ def test_device_poseidon_on_the_reference_parameter_sets(w):
     ctx.close()
 
 
-def test_poseidon_states_feed_the_prover_without_leaving_the_device():
-    """The witness of a Poseidon-heavy circuit never crosses PCIe: zkt_poseidon_hash_batch_dev writes every round's state
-    into a device buffer that IS the head of the variable map of zkt_prove_inputs (wires_on_device = 1, prove.rs:49-55
-    wire_evals on the device).  The circuit copies state words through gates and multiplies some of them; proof bytes ==
-    the oracle's proof over the oracle's own Poseidon trace."""
-    import zkt_plonk_amd as z
-    from oracle import plonk as P
-    cv = F.BN254
+def _gadget_params(cv, w):
+    """PoseidonParams for the oracle composer + the device handle's arguments: the reference's BN254 x3 / x4 / x5 sets, or
+    splitmix constants with a short schedule on BLS12-381 (its sets exist only as run-time generated constants)."""
+    from oracle import composer as OC
     p = cv.fr.p
-    w = 3
-    meta, rc, mds = _reference_params(w)
-    half_full, partial, arity, batch = meta["full_rounds"] // 2, meta["partial_rounds"], meta["arity"], 4
-    rounds = 2 * half_full + partial
-    ins = [field_elems(p, 9100 + b, arity) for b in range(batch)]
-    S = batch * (rounds + 1) * w
-    # ---- oracle: the same trace as the first S variables, then the gates
-    cs = P.ConstraintSystem(cv, [5, 6, 7], 8)
-    out_vars = []
-    for b in range(batch):
-        hsh, trace = OP.permute(p, w, half_full, partial, rc, mds, meta["domain_tag"], ins[b])
-        base = len(cs.values)
-        for row in trace:
-            for x in row:
-                cs.assign_variable(x)
-        out_vars.append(base + rounds * w + 1)                      # elements[1] after the last round = the hash
-        assert cs.values[out_vars[-1]] == hsh
-    assert len(cs.values) == S
-    for v in range(0, S, 5):
-        cs.arith_constrain(v, P.ZERO_VAR, v, q_l=1, q_o=-1)         # the state word, copied through a gate
-    acc = out_vars[0]
-    for v in out_vars[1:]:
-        acc = cs.mul_gate(acc, v)                                    # product of the hashes (new variables past S)
-    cs.set_variable_public(out_vars[0])
-    cs.set_variable_public(acc)
-    assert cs.check_satisfied()
-    n = cs.circuit_bound()
-    tau = 0xF00D
-    srs = K.srs_mont(cv, tau, n + 8)
-    be = K.CBackend(cv, srs)
-    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
-    blinders = field_elems(p, 31, P.NUM_BLINDERS)
-    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
-    # ---- device: Poseidon states straight into the variable map
+    if cv.name == "bn254":
+        meta, rc, mds = _reference_params(w)
+        return OC.PoseidonParams(p, w, meta["full_rounds"] // 2, meta["partial_rounds"], rc, mds, meta["domain_tag"])
+    half_full, partial = 2, 5
+    rc = field_elems(p, 40 + w, (2 * half_full + partial) * w)
+    mds = [field_elems(p, 400 + 7 * w + i, w) for i in range(w)]
+    return OC.PoseidonParams(p, w, half_full, partial, rc, mds)
+
+
+def _load(ctx, cv, prm):
+    return ctx.poseidon_load(prm.width, prm.half_full, prm.partial, K.fr_to_mont(cv, prm.rc),
+                             K.fr_to_mont(cv, [x for row in prm.mds for x in row]), K.fr_to_mont(cv, [prm.domain_tag])[0])
+
+
+@pytest.mark.parametrize("cvname,w", [("bn254", 3), ("bn254", 4), ("bn254", 5), ("bls12_381", 2), ("bls12_381", 5), ("bls12_381", 8)])
+def test_gadget_witness_equals_the_composers_variables(cvname, w):
+    """k_poseidon_gadget against the oracle's gate-by-gate restatement of PlonkSpecRef on the composer
+    (oracle/composer.py: spec.rs:174-219 on constraint_system/arithmetic.rs:15-104): for every hash the
+    2 half_full (3W + W^2) + partial (3 + W^2) values the composer assigns, in its allocation order -- 804 / 1288 / 1888
+    on the reference's x3 / x4 / x5 -- for arities 0, 1 and W - 1, inputs given as values and as variable indices
+    (Variable::Zero included), dense and scattered trace bases."""
+    import zkt_plonk_amd as z
+    import zkt_plonk_amd._lib as L
+    from oracle import composer as OC
+    cv = F.CURVES[cvname]
+    p = cv.fr.p
+    prm = _gadget_params(cv, w)
+    per = prm.gates_per_hash
+    if cvname == "bn254":
+        assert per == {3: 804, 4: 1288, 5: 1888}[w]
     ctx = z.Context(cv.name, 0)
-    ctx.srs_load(srs)
-    z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) if pk.polys[k] else np.zeros((0, 4), np.uint64)
-                                          for k in z.PK_ORDER})
-    h = ctx.poseidon_load(w, half_full, partial, K.fr_to_mont(cv, rc), K.fr_to_mont(cv, [x for row in mds for x in row]),
-                          K.fr_to_mont(cv, [meta["domain_tag"]])[0])
+    h = _load(ctx, cv, prm)
+    assert ctx.poseidon_gadget_vars_per_hash(h) == per
+    for arity in sorted({0, 1, w - 1}):
+        batch = 150
+        ins = [field_elems(p, 8100 + 3 * b + arity, arity) for b in range(batch)]
+        ins[0] = [0] * arity
+        ins[1] = [p - 1] * arity
+        # (a) input values, dense traces behind a gap of 5 variables
+        n_vars = 5 + batch * per
+        d_vars, d_in, d_out = ctx.alloc(n_vars * 32), ctx.alloc(max(1, batch * arity) * 32), ctx.alloc(batch * 32)
+        ctx.upload(d_vars, np.zeros((n_vars, 4), np.uint64))
+        if arity:
+            ctx.upload(d_in, K.fr_to_mont(cv, [x for row in ins for x in row]))
+        ctx.poseidon_gadget_witness_dev(h, batch, arity, d_vars, n_vars, d_inputs=d_in if arity else 0, trace_base0=5,
+                                        d_out_hashes=d_out)
+        ctx.poseidon_gadget_check(h)
+        got = K.fr_from_mont(cv, ctx.download(d_vars, (n_vars, 4)))
+        hashes = K.fr_from_mont(cv, ctx.download(d_out, (batch, 4)))
+        assert got[:5] == [0] * 5
+        for b in (0, 1, 2, 77, batch - 1):
+            want = OC.gadget_trace(prm, ins[b])
+            assert got[5 + b * per:5 + (b + 1) * per] == want, (arity, b)
+            assert hashes[b] == prm.native(ins[b]) == want[per - 1 - (w - 2) * w]
+            # ... and the composer itself, gate by gate (the values it assigns while synthesising the hash)
+            if b < 3:
+                cs = OC.Composer(cv, [1], 8)
+                vs = [cs.assign_variable(x) for x in ins[b]]
+                out = OC.poseidon_hash(cs, prm, [cs.lt(v) for v in vs])
+                assert cs.values[arity:] == want and cs.n_gates == per and cs.check_satisfied()
+                assert out.var == arity + per - 1 - (w - 2) * w and (out.coeff, out.offset) == (1, 0)
+        # (b) inputs as variable indices (every third hash's first input = Variable::Zero), traces at scattered bases
+        if arity:
+            n_vars = batch * arity + batch * (per + 3)
+            vals = [x for row in ins for x in row]
+            idx = np.arange(batch * arity, dtype=np.uint32).reshape(batch, arity)
+            idx[::3, 0] = 0xFFFFFFFF
+            bases = np.array([batch * arity + (batch - 1 - b) * (per + 3) + 2 for b in range(batch)], dtype=np.uint32)
+            d_v2, d_idx, d_base = ctx.alloc(n_vars * 32), ctx.alloc(idx.nbytes), ctx.alloc(bases.nbytes)
+            ctx.upload(d_v2, np.concatenate([K.fr_to_mont(cv, vals), np.zeros((n_vars - len(vals), 4), np.uint64)]))
+            ctx.upload(d_idx, idx)
+            ctx.upload(d_base, bases)
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base)
+            ctx.poseidon_gadget_check(h)
+            got2 = K.fr_from_mont(cv, ctx.download(d_v2, (n_vars, 4)))
+            assert got2[:batch * arity] == vals
+            for b in (0, 1, 2, 3, 76, batch - 1):
+                row = [0 if (b % 3 == 0 and k == 0) else ins[b][k] for k in range(arity)]
+                assert got2[int(bases[b]):int(bases[b]) + per] == OC.gadget_trace(prm, row), (arity, b)
+                assert got2[int(bases[b]) - 2:int(bases[b])] == [0, 0]
+            # an index outside the map: that hash is skipped, the flag is raised once and cleared
+            bases[7] = n_vars - per + 1
+            ctx.upload(d_base, bases)
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base)
+            with pytest.raises(L.ZktError):
+                ctx.poseidon_gadget_check(h)
+            ctx.poseidon_gadget_check(h)
+            idx[9, arity - 1] = n_vars
+            bases[7] = 0
+            ctx.upload(d_base, bases)
+            ctx.upload(d_idx, idx)
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base)
+            with pytest.raises(L.ZktError):
+                ctx.poseidon_gadget_check(h)
+            for d in (d_v2, d_idx, d_base):
+                ctx.free(d)
+        with pytest.raises(L.ZktError):      # dense traces that do not fit the map are refused on the host
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_vars, batch * per - 1, d_inputs=d_in if arity else 0)
+        if arity:
+            with pytest.raises(L.ZktError):  # both input forms / neither
+                ctx.poseidon_gadget_witness_dev(h, batch, arity, d_vars, n_vars)
+        for d in (d_vars, d_in, d_out):
+            ctx.free(d)
+    with pytest.raises(L.ZktError):
+        ctx.poseidon_gadget_witness_dev(h, 1, w, 1, 1, d_inputs=1)       # FullBuffer (spec.rs:253-257)
+    ctx.poseidon_free(h)
+    ctx.close()
+
+
+def _device_witness(ctx, cv, cs, gadget, corrupt=None):
+    """The composer's variable map with every Poseidon trace produced ON THE DEVICE: the host uploads only the variables the
+    gadget does not make (zeros where the traces go), ONE k_poseidon_gadget launch (zkt_plonk_amd.PoseidonGadget) fills
+    all the hashes' variables from their input variables' indices.  Returns the device pointer."""
+    per = gadget.vars_per_hash
     n_vars = len(cs.values)
-    d_vars, d_in, d_hash = ctx.alloc(n_vars * 32), ctx.alloc(batch * arity * 32), ctx.alloc(batch * 32)
-    ctx.upload(d_in, K.fr_to_mont(cv, [x for row in ins for x in row]))
-    ctx.poseidon_hash_batch_dev(h, d_in, batch, arity, d_hash, d_vars)           # states = variables [0, S)
-    ctx.upload(d_vars + S * 32, K.fr_to_mont(cv, cs.values[S:]))                 # the few host-made variables behind them
+    host = list(cs.values)
+    gadget.calls = []
+    for base, ins in cs.hash_calls:
+        assert all(co == 1 and off == 0 for (_, co, off) in ins), "gadget inputs are plain variables"
+        host[base:base + per] = [0] * per
+        out = gadget.hash(base, [0xFFFFFFFF if v == P.ZERO_VAR else v for (v, _, _) in ins])
+        assert out == base + per - 1 - (gadget.width - 2) * gadget.width
+    d_vars = ctx.alloc(n_vars * 32)
+    ctx.upload(d_vars, K.fr_to_mont(cv, host))
+    gadget.stage()
+    assert gadget.fill(d_vars, n_vars) == 1
+    if corrupt is not None:
+        v = K.fr_from_mont(cv, ctx.download(d_vars + corrupt * 32, (1, 4)))[0]
+        ctx.upload(d_vars + corrupt * 32, K.fr_to_mont(cv, [(v + 1) % cv.fr.p]))
+    return d_vars
+
+
+def _gadget(z, ctx, cv, prm):
+    return z.PoseidonGadget(ctx, prm.width, prm.half_full, prm.partial, K.fr_to_mont(cv, prm.rc),
+                            K.fr_to_mont(cv, [x for row in prm.mds for x in row]), K.fr_to_mont(cv, [prm.domain_tag])[0])
+
+
+def _prove_from_device_witness(ctx, cv, cs, d_vars, blinders, vk_n, vk_commits):
+    import zkt_plonk_amd as z
     to_idx = lambda ws: np.array([0xFFFFFFFF if v == P.ZERO_VAR else v for v in ws], dtype=np.uint32)
     d_idx = []
     for ws in (cs.w_l, cs.w_r, cs.w_o):
@@ -184,9 +274,118 @@ def test_poseidon_states_feed_the_prover_without_leaving_the_device():
         ctx.upload(d, to_idx(ws))
         d_idx.append(d)
     pi_pos = sorted(cs.pi)
-    prep = ctx.prepare_vars_dev(d_vars, n_vars, d_idx[0], d_idx[1], d_idx[2], cs.n_gates, K.fr_to_mont(cv, cs.table), pi_pos,
-                                K.fr_to_mont(cv, [cs.pi[k] for k in pi_pos]), K.fr_to_mont(cv, blinders))
-    tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk"), vk.n, vk.commits)
-    assert ctx.prove_prepared(prep, tr) == want
-    ctx.poseidon_free(h)
+    prep = ctx.prepare_vars_dev(d_vars, len(cs.values), d_idx[0], d_idx[1], d_idx[2], cs.n_gates, K.fr_to_mont(cv, cs.table),
+                                pi_pos, K.fr_to_mont(cv, [cs.pi[k] for k in pi_pos]), K.fr_to_mont(cv, blinders))
+    tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * cv.fq.limbs64), vk_n, vk_commits)
+    try:
+        return ctx.prove_prepared(prep, tr)
+    finally:
+        for d in d_idx:
+            ctx.free(d)
+
+
+from oracle import plonk as P
+
+
+@pytest.mark.parametrize("w", [3, 4, 5])
+def test_poseidon_gadget_circuit_proves_from_the_device_made_witness(w):
+    """A circuit of REAL Poseidon gadgets on the reference's x3 / x4 / x5 sets, built by the oracle composer gate by gate
+    (chained hashes of different arities, the last one public): its witness is produced on the device -- the host
+    uploads the free variables only, k_poseidon_gadget fills every gate output -- and goes to zkt_prove as the variable
+    map + the composer's w_l / w_r / w_o (wires_on_device = 1).  Proof bytes == the oracle's proof over the composer's own
+    values.  One flipped intermediate (an x^4 in a partial round; a running MDS sum) makes the proof fail: every gadget
+    variable is constrained."""
+    import zkt_plonk_amd as z
+    import zkt_plonk_amd._lib as L
+    from oracle import composer as OC
+    cv = F.BN254
+    p = cv.fr.p
+    prm = _gadget_params(cv, w)
+    per = prm.gates_per_hash
+    cs = OC.Composer(cv, [5, 6, 7], 8)
+    free = [cs.assign_variable(x) for x in field_elems(p, 9200 + w, 2 * (w - 1) + 2)]
+    h1 = OC.poseidon_hash(cs, prm, [cs.lt(v) for v in free[:w - 1]])            # full arity
+    h2 = OC.poseidon_hash(cs, prm, [cs.lt(free[w - 1])])                        # one input
+    h3 = OC.poseidon_hash(cs, prm, [])                                          # none
+    h4 = OC.poseidon_hash(cs, prm, [cs.lt(v) for v in free[w:2 * w - 1]][:w - 1])
+    prod = cs.mul_gate(h1, h2)
+    s = cs.add_gate(cs.lt(prod), h3)
+    cs.set_variable_public(h4)
+    cs.set_variable_public(cs.lt(s))
+    assert cs.n_gates == 4 * per + 4 and len(cs.hash_calls) == 4 and cs.check_satisfied()
+    n = cs.circuit_bound()
+    tau = 0xF00D
+    srs = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    blinders = field_elems(p, 31 + w, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    ctx = z.Context(cv.name, 0)
+    ctx.srs_load(srs)
+    z.GpuProver(ctx, n.bit_length() - 1, {k: K.fr_to_mont(cv, pk.polys[k]) if pk.polys[k] else np.zeros((0, 4), np.uint64)
+                                          for k in z.PK_ORDER})
+    g = _gadget(z, ctx, cv, prm)
+    assert g.vars_per_hash == per
+    d_vars = _device_witness(ctx, cv, cs, g)
+    assert K.fr_from_mont(cv, ctx.download(d_vars, (len(cs.values), 4))) == cs.values      # the whole map, value by value
+    got = _prove_from_device_witness(ctx, cv, cs, d_vars, blinders, vk.n, vk.commits)
+    assert got == want
+    assert P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), [cs.pi[k] for k in sorted(cs.pi)])
+    ctx.free(d_vars)
+    # a wrong intermediate cannot prove: x^4 of the s-box of the first partial round of hash 2, and a running sum of hash 4
+    W = w
+    x4_partial = cs.hash_calls[1][0] + prm.half_full * (3 * W + W * W) + 1
+    mds_sum = cs.hash_calls[3][0] + 3 * W + W + 1
+    for bad in (x4_partial, mds_sum):
+        d_bad = _device_witness(ctx, cv, cs, g, corrupt=bad)
+        with pytest.raises(L.ZktError) as e:
+            _prove_from_device_witness(ctx, cv, cs, d_bad, blinders, vk.n, vk.commits)
+        assert e.value.code == 9   # ZKT_ERR_QUOTIENT_TOO_SHORT: the circuit is not satisfied
+        ctx.free(d_bad)
+    g.close()
+    ctx.close()
+
+
+def test_config0_the_withdraw_circuit_itself_at_2_14():
+    """BASELINE.json configs[0] literally: WithdrawCircuit (circuits/src/withdraw.rs:57-150) on BN254 with Poseidon x4, one
+    note, HEIGHT 7 = 15 640 gates -> n = 2^14, synthesised by the oracle composer statement by statement (Poseidon
+    commitments / nullifier / leaves, the Merkle path gadget, the identifier lookup, the 64-bit range and balance rows; 5
+    public inputs in the CLI's order).  The 12 hashes' 15 456 variables are made on the device, the other 148 come from
+    the host; proof bytes == the CPU oracle's array prover, the verifier accepts with the public inputs the CLI would
+    pass (bin/src/main.rs:263-269)."""
+    import zkt_plonk_amd as z
+    from oracle import composer as OC, fastplonk as FP
+    cv = F.BN254
+    p = cv.fr.p
+    prm = _gadget_params(cv, 4)
+    cs, public_inputs = OC.withdraw_instance(cv, prm, inputs=1, height=7, seed=11)
+    assert cs.n_gates == OC.withdraw_gate_count(prm, 1, 7) == 15640 and cs.check_satisfied()
+    assert len(cs.hash_calls) == 3 + 7 + 2
+    n = cs.circuit_bound()
+    assert n == 1 << 14
+    tau = 0x5EED5EED1234567890ABCDEF % p
+    srs = K.srs_mont(cv, tau, n + 8)
+    be = K.CBackend(cv, srs)
+    evals = {k: K.fr_to_mont(cv, v) for k, v in P.setup_evals(be, cs).items()}
+    keys = FP.setup(cv, srs, 14, evals)
+    vk = keys.verifier_key(cv, cs.pi.keys())
+    assert [cs.pi[k] for k in sorted(cs.pi)] == public_inputs
+    a, b, c = cs.wire_evals(cs.n_gates)
+    blinders = field_elems(p, 1414, P.NUM_BLINDERS)
+    want = FP.prove(cv, srs, keys, K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
+                    dict(cs.pi), P.new_seeded_transcript(cv, vk), blinders)
+    ctx = z.Context(cv.name, 0)
+    ctx.srs_load(srs)
+    prover, commits = z.GpuProver.setup(ctx, 14, evals)
+    g = _gadget(z, ctx, cv, prm)
+    d_vars = _device_witness(ctx, cv, cs, g)
+    assert K.fr_from_mont(cv, ctx.download(d_vars, (len(cs.values), 4))) == cs.values
+    got = _prove_from_device_witness(ctx, cv, cs, d_vars, blinders, vk.n, vk.commits)
+    assert got == want and len(got) == 802
+    assert P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), public_inputs)
+    bad = list(public_inputs)
+    bad[1] = (bad[1] + 1) % p                                  # another nullifier
+    assert not P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), bad)
+    ctx.free(d_vars)
+    g.close()
     ctx.close()

@@ -1,12 +1,13 @@
 #!/bin/bash
 # HBM traffic of the hot kernels from the TCC counters (MI355X_MICROARCH.md "HBM": separate passes for
 # FETCH_SIZE and WRITE_SIZE; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x).
-# usage (on the GPU box): bash tools/pmc_traffic.sh  -> gpurun_out/pmc_traffic_*.csv
+# usage (on the GPU box): [BENCH_ARGS=...] bash tools/pmc_traffic.sh  -> stdout (redirect into gpurun_out/pmc_traffic_<tag>.txt)
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_$ctr -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+  rm -rf $R/gpurun_out/pmc_$ctr
+  rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_$ctr -- python3 $R/bench.py $BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-latency > /dev/null 2>&1
 done
 cd $R
 python3 - <<'PY'

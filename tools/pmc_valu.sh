@@ -5,11 +5,12 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-latency"
+ARGS="$BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
 rocprofv3 -L > $R/gpurun_out/counters_avail.txt 2>&1
 G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES"
 G2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"
 G3="GRBM_GUI_ACTIVE GRBM_COUNT SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM SQ_THREAD_CYCLES_VALU"
+rm -rf $R/gpurun_out/pmc_valu_1 $R/gpurun_out/pmc_valu_2 $R/gpurun_out/pmc_valu_3
 i=0
 for G in "$G1" "$G2" "$G3"; do
   i=$((i+1))

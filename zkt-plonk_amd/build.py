@@ -31,8 +31,8 @@ def _headers_mtime():
     return m
 
 
-def _compile(src, hdr_m, force, extra):
-    obj = os.path.join(OBJ, src + ".o")
+def _compile(src, hdr_m, force, extra, obj_dir=None):
+    obj = os.path.join(obj_dir or OBJ, src + ".o")
     sp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_m):
         return obj, False
@@ -47,22 +47,33 @@ def _compile(src, hdr_m, force, extra):
     return obj, True
 
 
-def build(force: bool = False, extra_flags=None, jobs: int = 4) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, extra_flags=None, jobs: int = 4, lib: str = None, obj_dir: str = None) -> str:
+    lib = lib or LIB
+    obj_dir = obj_dir or OBJ
+    os.makedirs(obj_dir, exist_ok=True)
     hdr_m = _headers_mtime()
     extra = list(extra_flags or [])
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        res = list(ex.map(lambda s: _compile(s, hdr_m, force, extra), srcs))
+        res = list(ex.map(lambda s: _compile(s, hdr_m, force, extra, obj_dir), srcs))
     objs = [o for o, _ in res]
     # relink whenever an object is newer than the library (an object compiled by hand counts too)
-    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    stale = not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs)
     if force or stale or any(ch for _, ch in res):
-        cmd = ["hipcc", "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = ["hipcc", "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
+
+
+def build_experiments(force: bool = False, extra_flags=None) -> str:
+    """The A/B variant: same sources with -DZKT_EXPERIMENTS (environment knobs honoured, csrc/ctx.hpp exp_env) into
+    _ab/libzkt_exp.so; run it with ZKT_LIB_PATH.  Never loaded by default."""
+    ab = os.path.join(HERE, "..", "_ab")
+    os.makedirs(ab, exist_ok=True)
+    return build(force, ["-DZKT_EXPERIMENTS"] + list(extra_flags or []), lib=os.path.join(ab, "libzkt_exp.so"),
+                 obj_dir=os.path.join(HERE, "_obj_exp"))
 
 
 # ---- host-side sanitizer build ------------------------------------------------------------------------------------
@@ -122,4 +133,4 @@ def build_host_sanitized(force: bool = False, jobs: int = 4) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_experiments(force="--force" in sys.argv) if "--exp" in sys.argv else build(force="--force" in sys.argv))

@@ -1,5 +1,7 @@
 // C-ABI entry points: context, memory plumbing, Domain seam (see include/zkt_plonk.h).
 #include "ctx.hpp"
+
+#include <cstdlib>
 #include "hostinv.hpp"
 #include "ec.hpp"
 #include "hostec.hpp"
@@ -10,6 +12,15 @@ namespace zkt {
 
 void circuit_release(zkt_ctx* c);   // prover.hip
 void msm_release(zkt_ctx* c);       // msm.hip
+
+const char* exp_env(const char* name) {
+#ifdef ZKT_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 int set_err(zkt_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;

@@ -66,6 +66,11 @@ struct zkt_ctx {
 
 namespace zkt {
 
+// Experiment knobs (A/B runs of tools/ab_*.sh) are read from the environment ONLY by libraries built with
+// -DZKT_EXPERIMENTS (zkt-plonk_amd/build.py build_experiments() -> _ab/libzkt_exp.so); the shipped library never looks
+// at the environment, so a stray variable cannot change or break a proof.
+const char* exp_env(const char* name);
+
 int set_err(zkt_ctx* c, int code, const std::string& msg);
 int hip_fail(zkt_ctx* c, hipError_t e, const char* what);
 

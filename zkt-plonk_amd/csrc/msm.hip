@@ -875,6 +875,10 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     int cb = lg - 2;
     if (cb < 8) cb = 8;
     if (cb > 18) cb = 18;
+    if (const char* e = exp_env("ZKT_MSM_CBITS")) {   // experiment: another digit width (fewer windows, more buckets)
+        const int f = atoi(e);
+        if (f >= 8 && f <= MSM_MAX_Y) cb = f;
+    }
     {   // W windows of width cmax or cmax-1 covering exactly lambda+1 bits
         const int total = R::BITS + 1;
         const int W = (total + cb - 1) / cb;
@@ -939,9 +943,11 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         int blocks_per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
-        if (const char* e = getenv("ZKT_MSM_ACC_LDS")) {   // experiment: cap the resident workgroups through dynamic LDS
-            st->acc_lds = (size_t)atoi(e) * 1024;
-            (void)hipFuncSetAttribute((const void*)k_msm_accumulate<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->acc_lds);
+        if (const char* e = exp_env("ZKT_MSM_ACC_LDS")) {   // experiment: cap the resident workgroups through dynamic LDS
+            const int kb = atoi(e);
+            if (kb < 0 || kb > 160) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "ZKT_MSM_ACC_LDS: 0 .. 160 (KiB)");
+            st->acc_lds = (size_t)kb * 1024;
+            ZKT_HIP(c, hipFuncSetAttribute((const void*)k_msm_accumulate<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st->acc_lds));
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_msm_accumulate<C>, 256, st->acc_lds) == hipSuccess &&
             blocks_per_cu > 0 && cus > 0)
@@ -952,7 +958,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         // ended a whole accumulation late (+8 % on the kernel); with two, the dispatcher gives the delayed CUs fewer of
         // the second half.  (ZKT_MSM_OVER = 1 .. 8 overrides the factor for experiments.)
         int over = 2;
-        if (const char* e = getenv("ZKT_MSM_OVER")) {
+        if (const char* e = exp_env("ZKT_MSM_OVER")) {
             const int f = atoi(e);
             if (f >= 1 && f <= 8) over = f;
         }

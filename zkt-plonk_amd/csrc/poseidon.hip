@@ -1,8 +1,14 @@
-// Batched Poseidon permutation over the scalar field: the witness-side arithmetic of the reference's hash gadget
-// (plonk-hashing/src/hasher/poseidon/spec.rs:18-111 rounds, :267-316 round schedule, :239-265 input
-// layout).  One thread per hash; with `out_states` every round's state is kept, which is what a composer needs to
-// fill the variables of its Poseidon gates for a whole batch of Merkle paths / notes at once.
-// Constants are the caller's (the reference generates them at run time, constants.rs:27: there is no table to pin).
+// Batched Poseidon over the scalar field: the witness-side arithmetic of the reference's hash gadget (SURVEY.md 8f.3;
+// plonk-hashing/src/hasher/poseidon/spec.rs:18-111 rounds, :267-316 round schedule, :239-265 input layout).  One thread
+// per hash.  Two kernels:
+//   k_poseidon_fx      the permutation (hash values, optionally every round's state): what NativePlonkSpecRef computes;
+//   k_poseidon_gadget  the WITNESS of the in-circuit gadget PlonkSpecRef (spec.rs:174-219): every value the composer
+//                      assigns while it synthesises one hash -- x^2, x^4, x^5 of each s-box (three mul_gates,
+//                      spec.rs:107-111) and each of the W^2 running sums of product_mds (one add_gate per term,
+//                      spec.rs:73-88) -- in the composer's allocation order, written into the variable map the prover
+//                      gathers its wires from (zkt_prove_inputs.variables).
+// Constants are the caller's (the reference generates them at run time, constants.rs:27, or parses the BN254 tables of
+// gadgets/src/poseidon).
 #include "ctx.hpp"
 
 #include <cstring>
@@ -16,8 +22,20 @@ constexpr int POSEIDON_MAX_WIDTH = 8;
 // Parameters are uploaded ONCE (zkt_poseidon_load) as 29-bit limbs in the kernels' own Montgomery radix R' = 2^261
 // ("H" form, fx.hpp): a product of two H values is an H value, so the whole permutation runs on unpacked limbs with no
 // conversion, and sum_i m[i][j] state[i] takes its products two at a time under one reduction (fx_mul2_inl).  Inputs are
-// converted on load (one product each), the hash / the optional per-round states on store.  Lazy bounds: a state word
-// is a sum of at most four products (< 8p), plus a round constant (< 9p); 81 p^2 < R' p, so no step needs a reduction.
+// converted on load (one product each), the hash / the optional per-round states on store.
+// Lazy bounds of k_poseidon_fx, valid for BOTH fields (R' / p is ~170 on BN254 but only ~71 on BLS12-381, so "state < 9p,
+// 81 p^2 < R' p" would NOT do there).  Write rho = R' / p >= 64 (static_assert below).  A product returns a b / R' + p'
+// with p' < p.  One operand of every MDS product is a canonical matrix entry (< p), the other a state word < S p, so a
+// pair product is < (2 S / rho + 1) p; a state word is the sum of at most four of them plus a round constant:
+// S <= 4 (2 S / rho + 1) + 1, i.e. S <= 5 / (1 - 8 / rho) <= 5.72.  The s-box squares a state word: S^2 p^2 <= 32.7 p^2 <
+// rho p^2 = R' p, and its later products take operands < 2p and < S p.  fx_mul2's contract (a b + c d < R' p) needs
+// 2 S p^2 < rho p^2: 11.5 < 64.
+template <class P>
+constexpr bool poseidon_lazy_bound_ok() {
+    // R' = 2^(29 L) >= 64 p  <=>  p < 2^(29 L - 6): the modulus has at most 29 L - 6 bits
+    return P::BITS <= 29 * FxP<P>::L - 6;
+}
+
 template <class P>
 struct PoseidonFxArgs {
     const uint32_t* rc;    // (2 half_full + partial) * W entries of 9 limbs (H form)
@@ -41,6 +59,7 @@ ZKT_D Fx<P> fx_load_limbs(const uint32_t* p) {
 template <class P, int W>
 __global__ __launch_bounds__(128) void k_poseidon_fx(PoseidonFxArgs<P> a) {
     static_assert(FxP<P>::L == 9, "scalar fields use nine limbs");
+    static_assert(poseidon_lazy_bound_ok<P>(), "lazy reduction needs R' >= 64 p (state < 5.72 p, its square < R' p)");
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= a.batch) return;
     Fx<P> st[W], nx[W];
@@ -102,6 +121,121 @@ __global__ __launch_bounds__(128) void k_poseidon_fx(PoseidonFxArgs<P> a) {
     fe_store<P>(a.out + h, fx_to_ark<P>(st[1]));   // spec.rs:315: elements[1]
 }
 
+// ---- the gadget's witness -------------------------------------------------------------------------------------------
+// Everything here stays in arkworks' own Montgomery form ("A": x R, R = 2^256), the form the variable map is stored in,
+// so no value is converted on its way out: products against an MDS entry take the entry in H form (A x H -> A), and a
+// product of two variables takes one of them shifted up by SH = 5 bits (A x 32 A / R' = A; the shift is two
+// instructions per limb, a conversion would be a product).  Every variable is canonical when it is stored, hence
+// < p when it is next used: p x 32 p < R' p on both fields.
+template <class P>
+struct PoseidonGadgetArgs {
+    const uint32_t* rc_a;      // round constants as A-form limbs (canonical)
+    const uint32_t* mds;       // H form, m[i][j] at (i * W + j)
+    uint32_t tag_a[FxP<P>::L];
+    const Fe<P>* inputs;       // batch * arity values, or null
+    const uint32_t* input_vars;// batch * arity indices into vars, or null
+    Fe<P>* vars;               // the variable map
+    uint64_t n_vars;
+    const uint32_t* trace_base;// per hash, or null: base0 + h * per_hash
+    uint64_t base0;
+    Fe<P>* out;                // optional: batch hash values
+    uint32_t* status;          // set to 1 when a hash was skipped (an index outside the map)
+    uint64_t batch;
+    int half_full, partial, arity;
+};
+
+// value * 2^SH on normalised limbs of a canonical value (32 p < 2^(29 L)); result normalised
+template <class P>
+ZKT_D Fx<P> fx_shl_sh(const Fx<P>& a) {
+    constexpr int L = FxP<P>::L, SH = FxP<P>::SH;
+    Fx<P> r;
+    r.l[0] = (a.l[0] << SH) & FxP<P>::MASK;
+#pragma unroll
+    for (int i = 1; i < L - 1; ++i) r.l[i] = ((a.l[i] << SH) | (a.l[i - 1] >> (29 - SH))) & FxP<P>::MASK;
+    r.l[L - 1] = (a.l[L - 1] << SH) | (a.l[L - 2] >> (29 - SH));
+    return r;
+}
+
+// a, b canonical A values -> a b as a canonical A value (mul_gate's assigned value, arithmetic.rs:95-99)
+template <class P>
+ZKT_D Fx<P> gadget_mul(const Fx<P>& a, const Fx<P>& b_shifted) {
+    return fx_cond_sub_p<P>(fx_mul<P>(a, b_shifted));
+}
+
+template <class P, int W>
+__global__ __launch_bounds__(128) void k_poseidon_gadget(PoseidonGadgetArgs<P> a) {
+    static_assert(FxP<P>::L == 9 && FxP<P>::SH == 5, "scalar fields: nine limbs, R' = 32 R");
+    static_assert(P::BITS + FxP<P>::SH < 29 * FxP<P>::L, "p * 2^SH * p < R' p");
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.batch) return;
+    const int rounds = 2 * a.half_full + a.partial;
+    const uint64_t per_hash = (uint64_t)2 * a.half_full * (3 * W + W * W) + (uint64_t)a.partial * (3 + W * W);
+    const uint64_t base = a.trace_base ? (uint64_t)a.trace_base[h] : a.base0 + h * per_hash;
+    bool ok = base <= a.n_vars && per_hash <= a.n_vars - base;
+    Fx<P> st[W], nx[W];
+    // reset + input (spec.rs:239-263): LTVariable::constant(domain_tag), the inputs, LTVariable::zero()
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) st[0].l[i] = a.tag_a[i];
+#pragma unroll
+    for (int i = 1; i < W; ++i) {
+        st[i] = fx_zero<P>();
+        if (i - 1 < a.arity) {
+            if (a.input_vars) {
+                const uint32_t v = a.input_vars[h * a.arity + (i - 1)];
+                if (v != ZKT_VARIABLE_ZERO) {
+                    if (v < a.n_vars) st[i] = fx_unpack<P>(fe_load<P>(a.vars + v));
+                    else ok = false;
+                }
+            } else {
+                st[i] = fx_unpack<P>(fe_load<P>(a.inputs + h * a.arity + (i - 1)));
+            }
+        }
+    }
+    if (!ok) {
+        atomicOr(a.status, 1u);
+        return;
+    }
+    Fe<P>* out = a.vars + base;
+    const uint32_t* rc = a.rc_a;
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const bool full = r < a.half_full || r >= a.half_full + a.partial;   // output_hash, spec.rs:267-316
+        // add_constant (spec.rs:194-200) is a lazy LTVariable transform: no gate, no variable; its value enters the
+        // gates that follow
+#pragma unroll
+        for (int i = 0; i < W; ++i) st[i] = fx_cond_sub_p<P>(fx_add<P>(st[i], fx_load_limbs<P>(rc + 9 * i)));
+        rc += 9 * W;
+        // power_of_5 (spec.rs:107-111): x^2 = mul(x, x), x^4 = mul(x^2, x^2), x^5 = mul(x^4, x): three variables
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            if (i == 0 || full) {
+                const Fx<P> xs = fx_shl_sh<P>(st[i]);
+                const Fx<P> x2 = gadget_mul<P>(st[i], xs);
+                fe_store<P>(out++, fx_pack<P>(x2));
+                const Fx<P> x4 = gadget_mul<P>(x2, fx_shl_sh<P>(x2));
+                fe_store<P>(out++, fx_pack<P>(x4));
+                st[i] = gadget_mul<P>(x4, xs);
+                fe_store<P>(out++, fx_pack<P>(st[i]));
+            }
+        }
+        // product_mds (spec.rs:73-88): for j, for i: val = add_gate(val, mul_constant(state[i], m[i][j])): W^2 variables
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            Fx<P> acc = fx_zero<P>();
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const Fx<P> t = fx_cond_sub_p<P>(fx_mul<P>(st[i], fx_load_limbs<P>(a.mds + 9 * (i * W + j))));
+                acc = fx_cond_sub_p<P>(fx_add<P>(acc, t));
+                fe_store<P>(out++, fx_pack<P>(acc));
+            }
+            nx[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) st[j] = nx[j];
+    }
+    if (a.out) fe_store<P>(a.out + h, fx_pack<P>(st[1]));   // spec.rs:315: elements[1]
+}
+
 }  // namespace zkt
 
 // the opaque handle of include/zkt_plonk.h: PoseidonConstants resident in HBM
@@ -109,7 +243,10 @@ struct zkt_poseidon {
     int curve = 0, width = 0, half_full = 0, partial = 0;
     void* d_rc = nullptr;    // limbs, H form
     void* d_mds = nullptr;
+    void* d_rc_a = nullptr;  // limbs, arkworks form (the gadget kernel's)
+    void* d_status = nullptr;// one word: a gadget launch skipped a hash (index outside the variable map)
     uint32_t tag[16] = {};
+    uint32_t tag_a[16] = {};
 };
 
 namespace zkt {
@@ -125,19 +262,43 @@ static void to_h_limbs(const uint64_t* src_mont, size_t count, std::vector<uint3
     }
 }
 
+// arkworks-form words -> canonical A-form limbs (no conversion: the same residue x R, unpacked)
+template <class P>
+static int to_a_limbs(const uint64_t* src_mont, size_t count, std::vector<uint32_t>& out) {
+    out.resize(count * 9);
+    for (size_t k = 0; k < count; ++k) {
+        Fe<P> v;
+        memcpy(v.v, src_mont + 4 * k, 32);
+        const Fx<P> x = fx_unpack<P>(v);
+        const Fx<P> cx = fx_cond_sub_p<P>(x);
+        for (int i = 0; i < 9; ++i) {
+            if (cx.l[i] != x.l[i]) return 1;   // not below the modulus
+            out[9 * k + i] = x.l[i];
+        }
+    }
+    return 0;
+}
+
 template <class P>
 static int poseidon_load_t(zkt_ctx* c, const zkt_poseidon_params& p, zkt_poseidon* h) {
     const int W = p.width, rounds = 2 * p.half_full_rounds + p.partial_rounds;
-    std::vector<uint32_t> rc, mds, tag;
+    std::vector<uint32_t> rc, mds, tag, rc_a, tag_a;
     to_h_limbs<P>(p.round_constants, (size_t)rounds * W, rc);
     to_h_limbs<P>(p.mds, (size_t)W * W, mds);
     to_h_limbs<P>(p.domain_tag, 1, tag);
+    if (to_a_limbs<P>(p.round_constants, (size_t)rounds * W, rc_a) || to_a_limbs<P>(p.domain_tag, 1, tag_a))
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon: a constant is not below the field modulus");
     for (int i = 0; i < 9; ++i) h->tag[i] = tag[i];
+    for (int i = 0; i < 9; ++i) h->tag_a[i] = tag_a[i];
     int rcode;
     if ((rcode = dev_alloc(c, &h->d_rc, rc.size() * 4))) return rcode;
     if ((rcode = dev_alloc(c, &h->d_mds, mds.size() * 4))) return rcode;
+    if ((rcode = dev_alloc(c, &h->d_rc_a, rc_a.size() * 4))) return rcode;
+    if ((rcode = dev_alloc(c, &h->d_status, 4))) return rcode;
+    ZKT_HIP(c, hipMemsetAsync(h->d_status, 0, 4, c->stream));
     ZKT_HIP(c, hipMemcpyAsync(h->d_rc, rc.data(), rc.size() * 4, hipMemcpyHostToDevice, c->stream));
     ZKT_HIP(c, hipMemcpyAsync(h->d_mds, mds.data(), mds.size() * 4, hipMemcpyHostToDevice, c->stream));
+    ZKT_HIP(c, hipMemcpyAsync(h->d_rc_a, rc_a.data(), rc_a.size() * 4, hipMemcpyHostToDevice, c->stream));
     ZKT_HIP(c, hipStreamSynchronize(c->stream));   // the staging vectors die with this call
     return ZKT_OK;
 }
@@ -174,6 +335,42 @@ static int poseidon_enqueue_t(zkt_ctx* c, const zkt_poseidon* h, const void* d_i
     return ZKT_OK;
 }
 
+template <class P, int W>
+static void poseidon_gadget_launch_w(zkt_ctx* c, const PoseidonGadgetArgs<P>& a) {
+    hipLaunchKernelGGL((k_poseidon_gadget<P, W>), dim3((unsigned)((a.batch + 127) / 128)), dim3(128), 0, c->stream, a);
+}
+
+template <class P>
+static int poseidon_gadget_enqueue_t(zkt_ctx* c, const zkt_poseidon* h, const zkt_poseidon_gadget_args& g) {
+    PoseidonGadgetArgs<P> a{};
+    a.rc_a = (const uint32_t*)h->d_rc_a;
+    a.mds = (const uint32_t*)h->d_mds;
+    for (int i = 0; i < 9; ++i) a.tag_a[i] = h->tag_a[i];
+    a.inputs = (const Fe<P>*)g.d_inputs;
+    a.input_vars = g.d_input_vars;
+    a.vars = (Fe<P>*)g.d_variables;
+    a.n_vars = g.n_vars;
+    a.trace_base = g.d_trace_base;
+    a.base0 = g.trace_base0;
+    a.out = (Fe<P>*)g.d_out_hashes;
+    a.status = (uint32_t*)h->d_status;
+    a.batch = g.batch;
+    a.half_full = h->half_full;
+    a.partial = h->partial;
+    a.arity = g.arity;
+    switch (h->width) {
+        case 2: poseidon_gadget_launch_w<P, 2>(c, a); break;
+        case 3: poseidon_gadget_launch_w<P, 3>(c, a); break;
+        case 4: poseidon_gadget_launch_w<P, 4>(c, a); break;
+        case 5: poseidon_gadget_launch_w<P, 5>(c, a); break;
+        case 6: poseidon_gadget_launch_w<P, 6>(c, a); break;
+        case 7: poseidon_gadget_launch_w<P, 7>(c, a); break;
+        default: poseidon_gadget_launch_w<P, 8>(c, a); break;
+    }
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+
 static int poseidon_check_params(zkt_ctx* c, const zkt_poseidon_params* p) {
     if (!p || !p->round_constants || !p->mds || !p->domain_tag) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
     // output_hash (spec.rs:267-316) always runs one full and one partial round before its `1..n` loops: a schedule with
@@ -202,6 +399,8 @@ int zkt_poseidon_load(zkt_ctx* c, const zkt_poseidon_params* p, zkt_poseidon** o
     if (rc) {
         dev_free(c, h->d_rc);
         dev_free(c, h->d_mds);
+        dev_free(c, h->d_rc_a);
+        dev_free(c, h->d_status);
         delete h;
         return rc;
     }
@@ -215,6 +414,8 @@ void zkt_poseidon_free(zkt_ctx* c, zkt_poseidon* h) {
         (void)hipStreamSynchronize(c->stream);
         dev_free(c, h->d_rc);
         dev_free(c, h->d_mds);
+        dev_free(c, h->d_rc_a);
+        dev_free(c, h->d_status);
     }
     delete h;
 }
@@ -229,6 +430,43 @@ int zkt_poseidon_hash_batch_dev(zkt_ctx* c, const zkt_poseidon* h, const void* d
     (void)hipSetDevice(c->device);
     if (c->curve == ZKT_CURVE_BN254) return poseidon_enqueue_t<Bn254Fr>(c, h, d_inputs, batch, arity, d_out_hashes, d_out_states);
     return poseidon_enqueue_t<Bls381Fr>(c, h, d_inputs, batch, arity, d_out_hashes, d_out_states);
+}
+
+size_t zkt_poseidon_gadget_vars_per_hash(const zkt_poseidon* h) {
+    if (!h) return 0;
+    const size_t W = (size_t)h->width;
+    return (size_t)2 * h->half_full * (3 * W + W * W) + (size_t)h->partial * (3 + W * W);
+}
+
+int zkt_poseidon_gadget_witness_dev(zkt_ctx* c, const zkt_poseidon* h, const zkt_poseidon_gadget_args* g) {
+    if (!c || !h || !g) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (h->curve != c->curve) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon parameters belong to another curve");
+    if (g->arity < 0 || g->arity > h->width - 1)
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon: arity <= width - 1 (spec.rs:253-257 FullBuffer)");
+    if (g->batch == 0) return ZKT_OK;
+    if (!g->d_variables) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null variable map");
+    if (g->arity && !g->d_inputs == !g->d_input_vars)
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: exactly one of d_inputs / d_input_vars");
+    if (g->n_vars > 0xFFFFFFFFull) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "variable indices are 32 bits wide");
+    const size_t per = zkt_poseidon_gadget_vars_per_hash(h);
+    if (!g->d_trace_base && (g->trace_base0 > g->n_vars || g->batch > (g->n_vars - g->trace_base0) / per))
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: the traces do not fit the variable map");
+    (void)hipSetDevice(c->device);
+    if (c->curve == ZKT_CURVE_BN254) return poseidon_gadget_enqueue_t<Bn254Fr>(c, h, *g);
+    return poseidon_gadget_enqueue_t<Bls381Fr>(c, h, *g);
+}
+
+int zkt_poseidon_gadget_check(zkt_ctx* c, const zkt_poseidon* h) {
+    if (!c || !h) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    (void)hipSetDevice(c->device);
+    uint32_t st = 0;
+    ZKT_HIP(c, hipMemcpyAsync(&st, h->d_status, 4, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    if (st) {
+        ZKT_HIP(c, hipMemsetAsync(h->d_status, 0, 4, c->stream));
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: a trace base or an input index lies outside the variable map");
+    }
+    return ZKT_OK;
 }
 
 // host-pointer convenience form: load, stage, run, download, release (every exit path frees what it took)

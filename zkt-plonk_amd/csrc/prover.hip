@@ -150,7 +150,7 @@ struct Prover {
     CircuitState& S;
     HostTranscript& tr;
     Prover(zkt_ctx* ctx, CircuitState& st, HostTranscript& t) : c(ctx), S(st), tr(t) {
-        trace_on = getenv("ZKT_HOST_TRACE") != nullptr;
+        trace_on = exp_env("ZKT_HOST_TRACE") != nullptr;
     }
     bool copy_fenced = false;   // the copy stream already waits for the main stream's earlier work (run(), cold path)
     // ZKT_HOST_TRACE=1: wall-clock marks of the host control path (where the GPU may be waiting for the host)
