@@ -54,7 +54,8 @@ FIELDS = {
 }
 K1, K2 = 7, 13
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAD_CYCLES = 4.4               # measured v_mad_u64_u32 cycles / wave-instr / SIMD (profiles/microbench_r01.txt)
+MAD_CYCLES = 4.7               # measured v_mad_u64_u32 cycles / wave-instr / SIMD at the 2-4 waves per SIMD the
+                               # accumulation holds (profiles/microbench_r03.txt; 4.4 is the 8-wave figure)
 CLOCK_HZ = 2.4e9
 N_SIMD = 256 * 4
 
@@ -485,8 +486,8 @@ def main():
     Lq = -(-32 * 2 * L // 29)                                      # 9 (BN254 Fq), 14 (BLS12-381 Fq)
     mads_per_add = 6 * 2 * Lq * Lq + 2 * (Lq * (Lq + 1) // 2 + Lq * Lq) + 3 * Lq * Lq
     mad_ceiling = N_SIMD * 64 * CLOCK_HZ / MAD_CYCLES               # v_mad_u64_u32 issue ceiling, lanes/s
-    traffic, traffic_src = pmc_traffic("k_msm_accumulate", args.curve, log_n)
-    valu_busy, valu_src = pmc_valu_busy("k_msm_accumulate", args.curve, log_n)
+    traffic, traffic_src = pmc_traffic("k_msm_accumulate", args.curve, log_n, args.workload)
+    valu_busy, valu_src = pmc_valu_busy("k_msm_accumulate", args.curve, log_n, args.workload)
     roofline = {
         "kernel": "k_msm_accumulate", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -680,58 +681,90 @@ def sharded_leg(z, par, dist, dev, args, fld, tau, evals, vk, host_w, table, pis
             "bytes_sent_per_gpu_per_proof": (bytes1 - bytes0) // args.steps, "backend": dist.get_backend()}
 
 
-def pmc_traffic(kernel, curve, log_n):
+def csrc_digest():
+    """sha256 over the library's sources (zkt-plonk_amd/csrc/*): what a committed counter profile is valid for.  The GPU
+    box has no .git, so staleness is decided on the sources themselves, not on commits."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zkt-plonk_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc", ".cpp", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_files(prefix, curve, log_n, workload):
+    """Committed counter summaries (tools/pmc_traffic.sh / pmc_valu.sh write a first line
+    `# curve=... log_n=... workload=... csrc_digest=...`) that were taken on THIS configuration, newest first, each with
+    the digest of the sources it was taken on."""
+    import glob
+    import re
+    out = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", prefix + "_r*.txt")):
+        with open(f) as fh:
+            head = fh.readline()
+        m = dict(re.findall(r"(\w+)=(\S+)", head)) if head.startswith("#") else {}
+        if m.get("curve") != curve or m.get("log_n") != str(log_n) or m.get("workload", workload) != workload:
+            continue
+        key = [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
+        out.append((key, f, m.get("csrc_digest")))
+    return [(f, dg) for _, f, dg in sorted(out, reverse=True)]
+
+
+def _static_source(f, dg):
+    return {"file": "profiles/" + os.path.basename(f), "static": True, "csrc_digest": dg,
+            "is": "rocprofv3 --pmc pass of this bench configuration on these very sources, committed; not measured in this run"}
+
+
+def pmc_traffic(kernel, curve, log_n, workload):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
     profiles/pmc_traffic_*.txt: FETCH_SIZE and WRITE_SIZE in separate runs, KiB per launch; on gfx950 FETCH_SIZE counts
     64-B units for the 128-B requests of wide coalesced loads, MI355X_MICROARCH.md).  The accumulation kernel's reads are
-    scattered 64-B points, so its raw FETCH_SIZE is taken as is.  Only valid for the default workload."""
-    if curve != "bn254" or log_n != 20:
-        return None, None
-    import glob
-    import re
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic_r*.txt"))):
+    scattered 64-B points, so its raw FETCH_SIZE is taken as is.  A profile counts only if it was taken on this curve,
+    size and workload AND on the sources the library is built from now: otherwise (None, reason)."""
+    cur = csrc_digest()
+    files = _pmc_files("pmc_traffic", curve, log_n, workload)
+    for f, dg in files:
+        if dg != cur:
+            continue
         for line in open(f):
             if line.startswith(kernel):
                 parts = line.split()
                 try:
-                    fetch_kib, write_kib = float(parts[-2]), float(parts[-1])
+                    return round((float(parts[-2]) + float(parts[-1])) * 1024.0), _static_source(f, dg)
                 except ValueError:
-                    continue
-                key = [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
-                if best is None or key >= best[0]:
-                    best = (key, (fetch_kib + write_kib) * 1024.0, os.path.basename(f))
-    if best is None:
-        return None, None
-    return round(best[1]), "profiles/" + best[2]
+                    pass
+    return None, {"static": True, "stale": True,
+                  "is": "no committed PMC pass matches this configuration and the current sources (csrc_digest %s; have %s)"
+                        % (cur, [(os.path.basename(f), dg) for f, dg in files][:3])}
 
 
-def pmc_valu_busy(kernel, curve, log_n):
+def pmc_valu_busy(kernel, curve, log_n, workload):
     """VALUBusy of `kernel` from the committed rocprofv3 PMC pass (tools/pmc_valu.sh -> profiles/pmc_valu_*.txt):
     SQ_ACTIVE_INST_VALU * 4 / (SIMDs * GRBM_GUI_ACTIVE per XCD) -- rocprof's own derived-metric formula, gfx950 has no
-    entry of its own.  Only valid for the default workload."""
-    if curve != "bn254" or log_n != 20:
-        return None, None
-    import glob
-    import re
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_valu_r*.txt"))):
-        cur, vals = None, {}
+    entry of its own.  Same validity rule as pmc_traffic."""
+    cur = csrc_digest()
+    files = _pmc_files("pmc_valu", curve, log_n, workload)
+    for f, dg in files:
+        if dg != cur:
+            continue
+        c, vals = None, {}
         for line in open(f):
-            if not line.startswith(" "):
-                cur = line.split()[0] if line.strip() else None
+            if line.startswith("#"):
                 continue
-            if cur is not None and cur.startswith(kernel):
+            if not line.startswith(" "):
+                c = line.split()[0] if line.strip() else None
+                continue
+            if c is not None and c.startswith(kernel):
                 parts = line.split()
                 if len(parts) == 2 and parts[0] in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"):
                     vals[parts[0]] = float(parts[1])
         if len(vals) == 2 and vals["GRBM_GUI_ACTIVE"] > 0:
-            key = [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
-            if best is None or key >= best[0]:
-                best = (key, vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * vals["GRBM_GUI_ACTIVE"] / 8.0), os.path.basename(f))
-    if best is None:
-        return None, None
-    return round(best[1], 4), "profiles/" + best[2]
+            return round(vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * vals["GRBM_GUI_ACTIVE"] / 8.0), 4), _static_source(f, dg)
+    return None, {"static": True, "stale": True,
+                  "is": "no committed PMC pass matches this configuration and the current sources (csrc_digest %s)" % cur}
 
 
 def cpu_baseline(ctx, curve, log_n, evals, wires, table, pi, blinders, vk_pts, gpu_proof, oracle_twin=None):

@@ -16,8 +16,8 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The built libraries are not tracked by git: on a fresh checkout build them first (hipcc cross-compiles gfx950
     without a GPU).  Nothing is built when they are already there."""
-    lib = os.path.join(ROOT, "zkt-plonk_amd", "libzkt_plonk_hip.so")
-    if not os.path.exists(lib):
+    libs = [os.path.join(ROOT, "zkt-plonk_amd", n) for n in ("libzkt_plonk_hip.so", "libzkt_comm_rccl.so")]
+    if not all(os.path.exists(lib) for lib in libs):
         import __graft_entry__ as g
         g.build()
 

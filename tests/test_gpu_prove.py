@@ -188,6 +188,18 @@ def _bench_workload(z, ctx, cv, log_n, tau):
     return evals, w, vk
 
 
+
+def _check_srs_ends(cv, tau, srs):
+    """The device-generated SRS against the oracle at BOTH ends: the first 64 powers by the oracle's generator, the last 64
+    as [tau^i mod r] G by double-and-add on Python integers (a sampled head alone would miss a drift along the key)."""
+    from oracle import curve as C
+    count = srs.shape[0]
+    assert np.array_equal(srs[:64], K.srs_mont(cv, tau, 64))
+    G = C.generator(cv)
+    want = [C.scalar_mul(cv, pow(tau, i, cv.fr.p), G) for i in range(count - 64, count)]
+    assert K.points_from_mont(cv, srs[count - 64:]) == want
+
+
 def _gpu_prove_arrays(z, ctx, cv, w, vk, blinders):
     tr = z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * cv.fq.limbs64)
     z.seed_transcript(tr, vk.n, vk.commits)
@@ -208,7 +220,7 @@ def test_headline_configs_proof_bytes_equal_cpu_oracle(cvname, log_n, ctxs):
     tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
     evals, w, vk = _bench_workload(z, ctx, cv, log_n, tau)
     srs = ctx.srs_download(0, n + 8)
-    assert np.array_equal(srs[:64], K.srs_mont(cv, tau, 64))
+    _check_srs_ends(cv, tau, srs)
     keys = FP.setup(cv, srs, log_n, evals, commitments=log_n <= 14)
     if log_n <= 14:
         assert keys.commits == vk.commits
@@ -289,6 +301,7 @@ def test_config4_bls12_381_2_22_proof_bytes_equal_cpu_oracle(ctxs):
     tau = 0x5EED5EED1234567890ABCDEF % cv.fr.p
     evals, w, vk = _bench_workload(z, ctx, cv, log_n, tau)
     srs = ctx.srs_download(0, n + 8)
+    _check_srs_ends(cv, tau, srs)
     keys = FP.setup(cv, srs, log_n, evals, commitments=False)
     assert FP.commit(cv, srs, keys.pk["q_c"]) == vk.commits["q_c"]
     blinders = field_elems(cv.fr.p, 2020, P.NUM_BLINDERS)

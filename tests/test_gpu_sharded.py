@@ -139,6 +139,20 @@ def test_torch_comm_device_path_on_one_rank():
     assert r.returncode == 0 and "DEVCOMM OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("leg", ["direct", "sharded"])
+def test_rccl_transport_of_the_c_abi(leg):
+    """libzkt_comm_rccl.so (include/zkt_comm_rccl.h), the transport a host without torch links: `direct` calls the vtable's
+    all_gather with a world of one the way the library does (in place, out of place, overlapping, host buffers); `sharded`
+    proves ONE proof over 2 and 4 thread-ranks on this GPU whose communicators have device_buffers = 1, so that every exchange
+    of the sharded prover passes device pointers through capi.hip's device branch into a real ncclAllGather on the context's
+    stream (bytes == the CPU oracle's proof, exchange counts and sizes as designed).  In a process of its own, without
+    torch: RCCL and HIP are /opt/rocm's, as in a Rust host.  More than one RCCL rank remains UNVERIFIED ON HARDWARE."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZKT_SYSTEM_ROCM="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), leg], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL %s OK" % leg.upper() in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_sharded_mode_refuses_a_key_that_is_not_the_ranks_slice():
     """With a communicator attached, the whole key (zkt_srs_load) or another rank's slice would turn every combined
     commitment into a multiple of the right one: setup and prove refuse before any collective is entered."""

@@ -143,3 +143,30 @@ def test_point_serialization_roundtrip(cv):
     z = C.point_serialize_compressed(cv, None)
     assert z[-1] == 0x40 and C.point_deserialize_compressed(cv, z) is None
     assert len(C.point_to_bytes_uncompressed(cv, G)) == (65 if cv.name == "bn254" else 97)
+
+
+@pytest.mark.parametrize("f", [F.BN254_FR, F.BLS12_381_FR], ids=["bn254", "bls12_381"])
+def test_ntt_against_sympy(f):
+    """An independent implementation that is neither the reference's nor this repository's: sympy.discrete.transforms
+    ntt / intt (Cooley-Tukey over Z_p with the root g^((p-1)/n), g = sympy's smallest primitive root -- 5 for the BN254
+    scalar field, 7 for BLS12-381's: arkworks' GENERATOR).  oracle/ntt.py's fft / ifft and, through the
+    definition c_j g^j, coset_fft / coset_ifft must give the same numbers for n = 8, 64, 1024 (natural order both ways,
+    inverse scaled by 1/n)."""
+    from sympy import primitive_root
+    from sympy.discrete.transforms import ntt, intt
+    p = f.p
+    assert primitive_root(p) == f.generator
+    for n in (8, 64, 1024):
+        dom = Domain(f, n)
+        coeffs = field_elems(p, 4242 + n, n)
+        ev = dom.fft(coeffs)
+        assert ev == [int(x) for x in ntt(coeffs, prime=p)]
+        assert dom.ifft(ev) == coeffs == [int(x) for x in intt(ev, prime=p)]
+        short = coeffs[:n // 2 + 1]                       # zero-padded input, as the prover feeds it
+        assert dom.fft(short) == [int(x) for x in ntt(short + [0] * (n - len(short)), prime=p)]
+        g = f.generator
+        shifted = [c * pow(g, j, p) % p for j, c in enumerate(coeffs)]
+        cev = dom.coset_fft(coeffs)
+        assert cev == [int(x) for x in ntt(shifted, prime=p)]
+        assert dom.coset_ifft(cev) == coeffs
+        assert dom.coset_ifft(ev) == [int(x) * pow(g, -j, p) % p for j, x in enumerate(intt(ev, prime=p))]

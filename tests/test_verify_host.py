@@ -157,7 +157,9 @@ def test_checked_deserialisation_rejects_points_outside_the_prime_order_subgroup
 
 @pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
 def test_malformed_flag_bytes_are_refused(cv):
-    """ark-serialize SWFlags::from_u8: both flag bits at once is no encoding; one way only to write the point at infinity."""
+    """ark-serialize SWFlags::from_u8: both flag bits at once is no encoding.  Under the infinity flag GroupAffine::deserialize
+    (ark-ec 0.3, as recalled: "parity unpinned") parses x like any field element and then returns zero(): a canonical x is
+    ignored, an x at or above the modulus is an error."""
     cs, tau, srs, vk, proof = _proof(cv, "merlin", seed=13)
     pis = [cs.pi[k] for k in sorted(cs.pi)]
     raw = bytearray(proof.serialize(cv))
@@ -167,9 +169,14 @@ def test_malformed_flag_bytes_are_refused(cv):
     with pytest.raises(z.ZktError):
         _prepare(cv, "merlin", vk, srs, pis, bytes(both))
     inf_with_x = bytearray(raw)
-    inf_with_x[nb - 1] = (inf_with_x[nb - 1] & 0x3F) | 0x40                    # infinity flag over a non-zero x
-    with pytest.raises(z.ZktError):
-        _prepare(cv, "merlin", vk, srs, pis, bytes(inf_with_x))
+    inf_with_x[nb - 1] = (inf_with_x[nb - 1] & 0x3F) | 0x40                    # infinity flag over a non-zero x: ignored
     clean_inf = bytearray(raw)
-    clean_inf[:nb] = bytes(nb - 1) + b"\x40"                                    # the one encoding of the identity parses
-    _prepare(cv, "merlin", vk, srs, pis, bytes(clean_inf))
+    clean_inf[:nb] = bytes(nb - 1) + b"\x40"                                    # the usual encoding of the identity
+    got_x, inf_x = _prepare(cv, "merlin", vk, srs, pis, bytes(inf_with_x))
+    got_c, inf_c = _prepare(cv, "merlin", vk, srs, pis, bytes(clean_inf))
+    assert np.array_equal(got_x, got_c) and list(inf_x) == list(inf_c)
+    big_x = bytearray(raw)
+    big_x[:nb] = cv.fq.p.to_bytes(nb, "little")                                 # x = p under the infinity flag
+    big_x[nb - 1] |= 0x40
+    with pytest.raises(z.ZktError):
+        _prepare(cv, "merlin", vk, srs, pis, bytes(big_x))

@@ -10,6 +10,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/pmc_$ctr -- python3 $R/bench.py $BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-latency > /dev/null 2>&1
 done
 cd $R
+python3 tools/prof_header.py $BENCH_ARGS
 python3 - <<'PY'
 import csv, glob, collections
 out = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -5,6 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
+export BENCH_ARGS
 ARGS="$BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
 rocprofv3 -L > $R/gpurun_out/counters_avail.txt 2>&1
 G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES"
@@ -18,14 +19,16 @@ for G in "$G1" "$G2" "$G3"; do
 done
 cd $R
 python3 - $TAG <<'PY'
-import csv, glob, collections, sys
+import csv, glob, collections, sys, os
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_valu_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("zkt::", "")[-44:]
         out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for v in out.values() for c in v})
+import subprocess
 with open("gpurun_out/pmc_valu_%s.txt" % sys.argv[1], "w") as fo:
+    fo.write(subprocess.run([sys.executable, "tools/prof_header.py"] + os.environ.get("BENCH_ARGS", "").split(), capture_output=True, text=True).stdout)
     fo.write("per-launch averages, raw counter values (SQ_* cycle counters are quad-cycles summed over all SQs)\n")
     for k, v in sorted(out.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
         if sum(v.get("SQ_WAVE_CYCLES", [0])) < 1e6 and "accumulate" not in k and "ntt_pass" not in k: continue

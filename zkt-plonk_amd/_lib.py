@@ -46,6 +46,8 @@ def _share_torch_hip_runtime():
     initialises second finds no GPU.  When torch is installed, its copy is mapped first (by path, without importing
     torch), so that this library and torch resolve to the same runtime whatever the import order."""
     import importlib.util
+    if os.environ.get("ZKT_SYSTEM_ROCM"):       # a process that will never load torch (tests of the torch-free transport)
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

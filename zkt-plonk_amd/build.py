@@ -67,6 +67,22 @@ def build(force: bool = False, extra_flags=None, jobs: int = 4, lib: str = None,
     return lib
 
 
+COMM_SRC = os.path.join(HERE, "csrc_comm", "comm_rccl.cpp")
+COMM_LIB = os.path.join(HERE, "libzkt_comm_rccl.so")
+
+
+def build_comm(force: bool = False) -> str:
+    """libzkt_comm_rccl.so (include/zkt_comm_rccl.h): the optional RCCL transport; host code, links librccl."""
+    hdr = os.path.join(HERE, "..", "include", "zkt_comm_rccl.h")
+    src_m = max(os.path.getmtime(COMM_SRC), os.path.getmtime(hdr), _headers_mtime())
+    if force or not os.path.exists(COMM_LIB) or os.path.getmtime(COMM_LIB) < src_m:
+        cmd = ["hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", COMM_SRC, "-o", COMM_LIB, "-L/opt/rocm/lib", "-lrccl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building the RCCL transport failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return COMM_LIB
+
+
 def build_experiments(force: bool = False, extra_flags=None) -> str:
     """The A/B variant: same sources with -DZKT_EXPERIMENTS (environment knobs honoured, csrc/ctx.hpp exp_env) into
     _ab/libzkt_exp.so; run it with ZKT_LIB_PATH.  Never loaded by default."""

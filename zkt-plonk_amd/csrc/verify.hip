@@ -118,8 +118,10 @@ static bool g1_in_subgroup(const Affine<typename C::Fq>& p) {
 // both base fields have p = 3 mod 4, so sqrt(a) = a^((p + 1) / 4).  Checked deserialisation, as the reference's
 // verifier relies on it (proof.rs:308 "subgroup checks are done when the proof is deserialised"): SWFlags::from_u8
 // refuses both flag bits at once, x must be a canonical field element, the point must lie on the curve and in the
-// prime-order subgroup.  Under the infinity flag a non-zero x is refused as well: ark-serialize 0.3 (as recalled) does not
-// look at it, no honest encoder produces it, and the stricter reading cannot accept anything the reference rejects.
+// prime-order subgroup.  Under the infinity flag the x bytes are parsed like any field element (so they must be below the
+// modulus) and then ignored: GroupAffine::deserialize of ark-ec 0.3 reads (x, flags) with deserialize_with_flags and returns
+// zero() when flags.is_infinity() -- as recalled, the crate is not in this image ("parity unpinned"; r03 refused a non-zero x
+// there, which was stricter than the reference).
 template <class C>
 static bool decompress(const uint8_t* b, Affine<typename C::Fq>* out, bool* is_inf) {
     using Q = typename C::Fq;
@@ -128,9 +130,8 @@ static bool decompress(const uint8_t* b, Affine<typename C::Fq>* out, bool* is_i
     const uint8_t flags = b[nb - 1];
     if ((flags & 0xC0) == 0xC0) return false;
     if (flags & 0x40) {
-        for (size_t i = 0; i + 1 < nb; ++i)
-            if (b[i]) return false;
-        if (flags & 0x3F) return false;
+        Fe<Q> ignored;
+        if (!canonical_from_bytes<Q>(b, 2, &ignored)) return false;
         *is_inf = true;
         out->x = fe_zero<Q>();
         out->y = fe_zero<Q>();

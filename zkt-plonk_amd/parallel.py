@@ -106,6 +106,147 @@ class LocalComm:
             return 1
 
 
+_rccl_lib = None
+
+
+def rccl_lib():
+    """libzkt_comm_rccl.so (include/zkt_comm_rccl.h): the transport the C-ABI owns.  One copy of RCCL per process: when
+    PyTorch is installed its librccl.so.1 is mapped first (by path, without importing torch), like its HIP runtime in
+    _lib._share_torch_hip_runtime, so that this library, the prover and torch.distributed all resolve to the same one."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        import importlib.util
+        import os
+        from . import _lib
+        _lib.lib()                                              # the HIP runtime first (torch's copy if there is one)
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.submodule_search_locations and not os.environ.get("ZKT_SYSTEM_ROCM"):
+            path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+            if os.path.exists(path):
+                try:
+                    ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+                except OSError:
+                    pass
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzkt_comm_rccl.so")
+        if not os.path.exists(path):
+            raise ImportError("libzkt_comm_rccl.so is missing (%s): build it with __graft_entry__.build()" % path)
+        L = ctypes.CDLL(path)
+        L.zkt_comm_rccl_unique_id.argtypes = [ctypes.c_char_p]
+        L.zkt_comm_rccl_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.zkt_comm_rccl_vtable.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.zkt_comm_rccl_destroy.argtypes = [ctypes.c_void_p]
+        L.zkt_comm_rccl_destroy.restype = None
+        L.zkt_comm_rccl_last_error.argtypes = [ctypes.c_void_p]
+        L.zkt_comm_rccl_last_error.restype = ctypes.c_char_p
+        _rccl_lib = L
+    return _rccl_lib
+
+
+class RcclComm:
+    """zkt_comm_rccl (include/zkt_comm_rccl.h): ncclAllGather on the proving context's stream, no Python in the data path.
+    `unique_id()` on one rank, the 128 bytes to every rank (any channel), then RcclComm(id, rank, world, device) on each --
+    collective.  More than one rank has never run on hardware (one GPU per box in the development pool)."""
+    UNIQUE_ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(RcclComm.UNIQUE_ID_BYTES)
+        if rccl_lib().zkt_comm_rccl_unique_id(buf):
+            raise RuntimeError("ncclGetUniqueId failed")
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        from ._lib import CommVtable
+        assert len(unique_id) == self.UNIQUE_ID_BYTES
+        L = rccl_lib()
+        h = ctypes.c_void_p()
+        rc = L.zkt_comm_rccl_create(unique_id, rank, world, device, ctypes.byref(h))
+        if rc:
+            raise RuntimeError("zkt_comm_rccl_create failed with status %d" % rc)
+        self._h, self.rank, self.world = h, rank, world
+        self.vt = CommVtable()
+        if L.zkt_comm_rccl_vtable(self._h, ctypes.byref(self.vt)):
+            raise RuntimeError("zkt_comm_rccl_vtable failed")
+
+    def all_gather(self, send: int, recv: int, nbytes: int, on_device: bool, stream: int = 0) -> None:
+        """The vtable's callback, called the way the library calls it (raw pointers)."""
+        if self.vt.all_gather(self.vt.user, send, recv, nbytes, 1 if on_device else 0, stream):
+            raise RuntimeError("rccl all_gather: %s" % rccl_lib().zkt_comm_rccl_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            rccl_lib().zkt_comm_rccl_destroy(self._h)
+            self._h = None
+
+
+class RcclLocalGroup:
+    """Rehearsal on ONE GPU of the device path a multi-GPU job takes: `world` contexts driven by threads of one process,
+    communicator with device_buffers = 1.  Each rank's bytes enter the exchange through its OWN world-of-one RCCL
+    communicator (ncclAllGather on the context's stream, device pointers straight from the library: capi.hip
+    comm_all_gather_dev's device branch); what RCCL would carry over xGMI between the ranks is then copied device to device
+    (the ranks share the GPU).  Not a substitute for a multi-GPU run: it checks the pointers, sizes, in-place rule and
+    stream ordering the library hands a device transport, with a real RCCL call on them."""
+
+    def __init__(self, world: int, device: int = 0):
+        import threading
+        self.world, self.device = world, device
+        self.barrier = threading.Barrier(world)
+        self.recv = [0] * world
+        self.host_slots = [b""] * world
+
+    def comm(self, rank: int) -> "RcclLocalComm":
+        return RcclLocalComm(self, rank)
+
+
+class RcclLocalComm:
+    def __init__(self, group: RcclLocalGroup, rank: int):
+        from ._lib import CommVtable, ALL_GATHER_CB, lib
+        self.group, self.rank, self.world = group, rank, group.world
+        self.inner = RcclComm(RcclComm.unique_id(), 0, 1, group.device)
+        self.calls = self.device_calls = 0
+        self._L = lib()
+        self._cb = ALL_GATHER_CB(self._all_gather)
+        self.vt = CommVtable(None, rank, group.world, 1, self._cb)
+
+    def _all_gather(self, user, send, recv, nbytes, on_device, stream):
+        try:
+            g = self.group
+            self.calls += 1
+            if not on_device:
+                g.host_slots[self.rank] = ctypes.string_at(send, nbytes)
+                g.barrier.wait(timeout=120)
+                ctypes.memmove(recv, b"".join(g.host_slots), nbytes * self.world)
+                g.barrier.wait(timeout=120)
+                return 0
+            self.device_calls += 1
+            # my share into my slot of my receive buffer: a real ncclAllGather (world of one) on the context's stream
+            self.inner.all_gather(send, recv + self.rank * nbytes, nbytes, True, stream or 0)
+            g.recv[self.rank] = recv
+            g.barrier.wait(timeout=120)
+            hip = ctypes.CDLL("libamdhip64.so.7")                # by soname: the process's one HIP runtime, already mapped
+            hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            for q in range(self.world):
+                if q != self.rank:
+                    rc = hip.hipMemcpy(recv + q * nbytes, g.recv[q] + q * nbytes, nbytes, 3)   # hipMemcpyDeviceToDevice
+                    if rc:
+                        raise RuntimeError("hipMemcpy D2D failed: %d" % rc)
+            g.barrier.wait(timeout=120)
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            try:
+                self.group.barrier.abort()
+            except Exception:
+                pass
+            return 1
+
+    def close(self):
+        self.inner.close()
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) share of `total` independent units for `rank`; sizes differ by at most one."""
     assert 0 <= rank < world
