@@ -232,7 +232,7 @@ def withdraw_workload(z, torch, ctx, dev, fld, args, log_n):
     n_host = n_vars - len(L0.hash_calls) * hs.per_hash
     witness = {"hashes": len(L0.hash_calls), "vars_per_hash": hs.per_hash, "variables": n_vars, "host_made_variables": n_host,
                "device_made_variables": n_vars - n_host, "device_ms": round(min(dev_ms), 3),
-               "launches": len(gadget._staged),
+               "launches": len(gadget._staged), "hashes_per_launch": [c for _, c, _, _ in gadget._staged],
                "is": "k_poseidon_gadget: every variable the PlonkSpecRef gadget allocates (x^2, x^4, x^5 per s-box, the W^2 "
                      "running MDS sums per round) for all the circuit's hashes, written into the variable map in HBM; one "
                      "thread per hash, so a single proof's %d hashes are latency-bound (a proving service batches the hashes "

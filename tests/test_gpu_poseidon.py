@@ -239,8 +239,9 @@ def test_gadget_witness_equals_the_composers_variables(cvname, w):
 
 def _device_witness(ctx, cv, cs, gadget, corrupt=None):
     """The composer's variable map with every Poseidon trace produced ON THE DEVICE: the host uploads only the variables the
-    gadget does not make (zeros where the traces go), ONE k_poseidon_gadget launch (zkt_plonk_amd.PoseidonGadget) fills
-    all the hashes' variables from their input variables' indices.  Returns the device pointer."""
+    gadget does not make (zeros where the traces go), one k_poseidon_gadget launch per dependency level
+    (zkt_plonk_amd.PoseidonGadget: a hash fed by another hash's output waits for it) fills all the hashes' variables from
+    their input variables' indices.  Returns the device pointer."""
     per = gadget.vars_per_hash
     n_vars = len(cs.values)
     host = list(cs.values)
@@ -253,7 +254,7 @@ def _device_witness(ctx, cv, cs, gadget, corrupt=None):
     d_vars = ctx.alloc(n_vars * 32)
     ctx.upload(d_vars, K.fr_to_mont(cv, host))
     gadget.stage()
-    assert gadget.fill(d_vars, n_vars) == 1
+    assert gadget.fill(d_vars, n_vars) == len(gadget.levels())
     if corrupt is not None:
         v = K.fr_from_mont(cv, ctx.download(d_vars + corrupt * 32, (1, 4)))[0]
         ctx.upload(d_vars + corrupt * 32, K.fr_to_mont(cv, [(v + 1) % cv.fr.p]))
@@ -379,6 +380,7 @@ def test_config0_the_withdraw_circuit_itself_at_2_14():
     prover, commits = z.GpuProver.setup(ctx, 14, evals)
     g = _gadget(z, ctx, cv, prm)
     d_vars = _device_witness(ctx, cv, cs, g)
+    assert [len(l) for l in g.levels()] == [10, 2]        # the two leaf hashes take a commitment hash: second launch
     assert K.fr_from_mont(cv, ctx.download(d_vars, (len(cs.values), 4))) == cs.values
     got = _prove_from_device_witness(ctx, cv, cs, d_vars, blinders, vk.n, vk.commits)
     assert got == want and len(got) == 802

@@ -66,3 +66,24 @@ def test_shapes_fill_their_domains():
         assert (1 << (log_n - 1)) < gates <= (1 << log_n), (log_n, gates)
     with pytest.raises(ValueError):
         WW.layout(WW.reference_hasher(p, 3), WW.make_instance(WW.reference_hasher(p, 4), 1, 2, 1))
+
+
+def test_hash_calls_are_scheduled_by_dependency():
+    """zkt_plonk_amd.PoseidonGadget.levels (host logic, no GPU): hashes of one k_poseidon_gadget launch must be independent, so
+    a hash fed by another hash's output variable goes into a later launch.  In the withdraw circuit those are exactly the
+    leaf hashes (they take the commitment hash, withdraw.rs:91-94 and :141-144); the Merkle-path hashes take select outputs
+    (host-made variables) and stay in the first launch."""
+    from zkt_plonk_amd.poseidon import PoseidonGadget, VARIABLE_ZERO
+    p = F.BN254.fr.p
+    hs = WW.reference_hasher(p, 4)
+    L = WW.layout(hs, WW.make_instance(hs, 3, 5, seed=9))
+    g = PoseidonGadget.__new__(PoseidonGadget)
+    g.width, g.vars_per_hash, g.calls = hs.width, hs.per_hash, list(L.hash_calls)
+    lv = g.levels()
+    assert [len(x) for x in lv] == [len(L.hash_calls) - 4, 4]
+    assert all(len(L.hash_calls[k][1]) == 3 for k in lv[1])
+    g.calls = [(10, (1,)), (2000, (2, 3, 10 + 57)), (4000, (VARIABLE_ZERO,)), (6000, (2500, 4500))]
+    assert g.levels() == [[0, 2], [1], [3]]
+    g.calls = [(10, (2000,)), (2000, (11,))]
+    with pytest.raises(ValueError):
+        g.levels()

@@ -45,24 +45,51 @@ class PoseidonGadget:
         self.calls.append((first_variable, tuple(input_variables)))
         return first_variable + self.hash_var_offset
 
+    def levels(self) -> List[List[int]]:
+        """Calls grouped by dependency depth: a call whose input is a variable another call makes (the leaf hash of
+        circuits/src/withdraw.rs:91-94 takes the commitment hash) must run in a later launch than that call."""
+        import bisect
+        order = sorted(range(len(self.calls)), key=lambda k: self.calls[k][0])
+        bases = [self.calls[k][0] for k in order]
+        depth = [-1] * len(self.calls)
+
+        def maker(v):
+            at = bisect.bisect_right(bases, v) - 1
+            return order[at] if at >= 0 and v < bases[at] + self.vars_per_hash else None
+
+        def depth_of(k, seen=()):
+            if depth[k] < 0:
+                if k in seen:
+                    raise ValueError("Poseidon calls feed each other in a cycle")
+                deps = [maker(v) for v in self.calls[k][1] if v != VARIABLE_ZERO]
+                depth[k] = 1 + max([depth_of(d, seen + (k,)) for d in deps if d is not None], default=-1)
+            return depth[k]
+
+        out: List[List[int]] = []
+        for k in range(len(self.calls)):
+            d = depth_of(k)
+            while len(out) <= d:
+                out.append([])
+            out[d].append(k)
+        return out
+
     def stage(self):
         """Uploads the recorded calls' trace bases and input indices (structure of the circuit: the same for every witness).
         An absent input and an input that is Variable::Zero are the same LTVariable (Zero, 1, 0) (spec.rs:239-245 reset /
-        variable.rs:62-64), so calls of every arity go out as ONE launch of arity width - 1, padded with VARIABLE_ZERO."""
+        variable.rs:62-64), so calls of every arity go out together, as launches of arity width - 1 padded with
+        VARIABLE_ZERO: ONE launch per dependency level (`levels`), in order on the context's stream."""
         self.unstage()
-        if not self.calls:
-            return
         arity = self.width - 1
-        bases = np.array([b for b, _ in self.calls], dtype=np.uint32)
-        idx = np.full((len(self.calls), max(arity, 1)), VARIABLE_ZERO, dtype=np.uint32)
-        for k, (_, ins) in enumerate(self.calls):
-            idx[k, :len(ins)] = ins
-        d_base, d_idx = self.ctx.alloc(bases.nbytes), self.ctx.alloc(idx.nbytes)
-        self.ctx.upload(d_base, bases)
-        self.ctx.upload(d_idx, idx)
-        self._staged.append((arity, len(self.calls), d_base, d_idx if arity else 0))
-        if not arity:
-            self.ctx.free(d_idx)
+        for lvl in self.levels():
+            bases = np.array([self.calls[k][0] for k in lvl], dtype=np.uint32)
+            idx = np.full((len(lvl), max(arity, 1)), VARIABLE_ZERO, dtype=np.uint32)
+            for row, k in enumerate(lvl):
+                ins = self.calls[k][1]
+                idx[row, :len(ins)] = ins
+            d_base, d_idx = self.ctx.alloc(bases.nbytes), self.ctx.alloc(idx.nbytes)
+            self.ctx.upload(d_base, bases)
+            self.ctx.upload(d_idx, idx)
+            self._staged.append((arity, len(lvl), d_base, d_idx))
 
     def unstage(self):
         for _, _, d_base, d_idx in getattr(self, "_staged", []):
@@ -78,7 +105,7 @@ class PoseidonGadget:
         if not getattr(self, "_staged", None):
             self.stage()
         for arity, count, d_base, d_idx in self._staged:
-            self.ctx.poseidon_gadget_witness_dev(self._h, count, arity, d_variables, n_vars, d_input_vars=d_idx,
+            self.ctx.poseidon_gadget_witness_dev(self._h, count, arity, d_variables, n_vars, d_input_vars=d_idx if arity else 0,
                                                  d_trace_base=d_base)
         if check:
             self.ctx.poseidon_gadget_check(self._h)
