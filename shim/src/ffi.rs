@@ -79,6 +79,35 @@ extern "C" {
     pub fn zkt_poseidon_free(ctx: *mut ZktCtx, params: *mut c_void);
     pub fn zkt_poseidon_hash_batch_dev(ctx: *mut ZktCtx, params: *const c_void, d_inputs: *const c_void, batch: usize,
                                        arity: c_int, d_out_hashes: *mut c_void, d_out_states: *mut c_void) -> c_int;
+    pub fn zkt_poseidon_gadget_vars_per_hash(params: *const c_void) -> usize;
+    pub fn zkt_poseidon_gadget_witness_dev(ctx: *mut ZktCtx, params: *const c_void, args: *const ZktPoseidonGadgetArgs) -> c_int;
+    pub fn zkt_poseidon_gadget_check(ctx: *mut ZktCtx, params: *const c_void) -> c_int;
+    pub fn zkt_dev_alloc(ctx: *mut ZktCtx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
+    pub fn zkt_dev_free(ctx: *mut ZktCtx, dptr: *mut c_void) -> c_int;
+    pub fn zkt_dev_upload(ctx: *mut ZktCtx, dptr: *mut c_void, host: *const c_void, bytes: usize) -> c_int;
+}
+
+/// include/zkt_comm_rccl.h: the optional RCCL transport (libzkt_comm_rccl.so), INTEGRATION.md section 3c
+#[link(name = "zkt_comm_rccl")]
+extern "C" {
+    pub fn zkt_comm_rccl_unique_id(out: *mut u8) -> c_int;
+    pub fn zkt_comm_rccl_create(id: *const u8, rank: c_int, world: c_int, device: c_int, out: *mut *mut c_void) -> c_int;
+    pub fn zkt_comm_rccl_vtable(comm: *mut c_void, out: *mut ZktCommVtable) -> c_int;
+    pub fn zkt_comm_rccl_destroy(comm: *mut c_void);
+    pub fn zkt_comm_rccl_last_error(comm: *const c_void) -> *const c_char;
+}
+
+#[repr(C)]
+pub struct ZktPoseidonGadgetArgs {
+    pub batch: usize,
+    pub arity: c_int,
+    pub d_inputs: *const c_void,
+    pub d_input_vars: *const u32,
+    pub d_variables: *mut c_void,
+    pub n_vars: usize,
+    pub d_trace_base: *const u32,
+    pub trace_base0: usize,
+    pub d_out_hashes: *mut c_void,
 }
 
 #[repr(C)]

@@ -56,13 +56,15 @@ pub struct GpuDomain<F: FftField> {
 impl<F: FftField + PrimeField> GpuDomain<F> {
     /// `DomainCoeff<F>` also admits group elements, whose layout the library does not speak: only a vector of the scalar
     /// field itself (4 limbs per element, arkworks' Montgomery form) goes to the device, anything else stays on ark-poly.
+    /// `fft_in_place<T: DomainCoeff<F>>` cannot ask for `T: 'static`, so `core::any::TypeId` is out; `typeid::of` (the
+    /// `typeid` crate, sound for non-'static types) decides T == F exactly -- no name comparison, no size heuristics.
     fn is_scalar_vec<T>() -> bool {
-        core::mem::size_of::<T>() == core::mem::size_of::<F>() && core::any::type_name::<T>() == core::any::type_name::<F>()
+        typeid::of::<T>() == typeid::of::<F>()
     }
 
     /// inverse / coset as in include/zkt_plonk.h zkt_ntt; ark-poly resizes to n, the library zero-pads
     fn run<T: DomainCoeff<F>>(&self, v: &mut Vec<T>, inverse: c_int, coset: c_int) {
-        debug_assert!(Self::is_scalar_vec::<T>());
+        assert!(Self::is_scalar_vec::<T>(), "GpuDomain::run is for vectors of the scalar field itself");
         let n = self.inner.size();
         let in_len = v.len();
         v.resize(n, T::zero());
@@ -104,7 +106,8 @@ impl<F: FftField + PrimeField> plonk_core::util::EvaluationDomainExt<F> for GpuD
     fn group_gen(&self) -> F { self.inner.group_gen }
 }
 
-/// Repacks `GroupAffine { x, y, infinity }` (repr(Rust)) into x limbs || y limbs, (0, 0) for the identity.
+/// Repacks `GroupAffine { x, y, infinity }` (repr(Rust)) into x limbs || y limbs, (0, 0) for the identity (generic form;
+/// kzg::load_committer_key does the same through G1FromXY).
 pub fn pack_g1<G: ark_ec::AffineCurve>(pts: &[G], limbs: usize, xy: impl Fn(&G) -> (Vec<u64>, Vec<u64>)) -> Vec<u64> {
     let mut out = vec![0u64; pts.len() * 2 * limbs];
     for (i, p) in pts.iter().enumerate() {

@@ -1,7 +1,8 @@
 //! The body of `proof_system::prove` (plonk-core/src/proof_system/prove.rs:75-470) as ONE call into the library.
 //! `ProvingComposer` is crate-private in plonk-core, so this file is meant to live inside plonk-core as
 //! `src/gpu/prover.rs` under `cfg(feature = "gpu")`; it is kept here so that the binding is complete as source.
-//! UNCOMPILED (see lib.rs).
+//! UNCOMPILED (see lib.rs).  No stubs: the callbacks convert commitments through the function the caller supplies
+//! (`kzg::commitment_from_limbs::<E>`) and never unwind across the C boundary.
 use crate::{check, ffi, with_ctx};
 use ark_ff::{FftField, PrimeField};
 use ark_serialize::CanonicalDeserialize;
@@ -22,24 +23,43 @@ fn label(l: *const c_char) -> &'static str {
 
 unsafe fn frs<'a, F: PrimeField>(p: *const u64, k: usize) -> &'a [F] { core::slice::from_raw_parts(p as *const F, k) }
 
-/// `T: TranscriptProtocol<F, PC::Commitment>` behind the four callbacks of `zkt_transcript_vtable`
-pub fn vtable<F, PC, T>(transcript: &mut T, commitment_from_limbs: fn(*const u64, c_int) -> PC::Commitment) -> ffi::ZktTranscriptVtable
+/// What the callbacks find behind `user`: the transcript and the way from the library's (x, y) limbs to `PC::Commitment`
+/// (`kzg::commitment_from_limbs::<E>` for KZG10<E> / GpuKZG10<E>).  A callback that panics must not unwind into C: the
+/// panic is caught, remembered here and re-raised by `prove_gpu` after the library has returned.
+pub struct CallbackState<'t, F: PrimeField, PC: HomomorphicCommitment<F>, T: TranscriptProtocol<F, PC::Commitment>> {
+    transcript: &'t mut T,
+    commitment_from_limbs: fn(*const u64, c_int) -> PC::Commitment,
+    panic: Option<Box<dyn std::any::Any + Send + 'static>>,
+    _f: core::marker::PhantomData<F>,
+}
+
+fn guarded<F, PC, T>(u: *mut c_void, body: impl FnOnce(&mut CallbackState<'_, F, PC, T>))
 where
     F: PrimeField,
     PC: HomomorphicCommitment<F>,
     T: TranscriptProtocol<F, PC::Commitment>,
 {
-    // Rust closures cannot be `extern "C"`: each callback is a monomorphised function that recovers `&mut T` from `user`
-    // (and, for commitments, the conversion function from a static slot set just above); spelled out in INTEGRATION.md
-    // section 3.  What each one does:
-    //   append_u64(u, l, v)                 -> T::append_u64(label(l), v)
-    //   append_scalars(u, l, p, k, single)  -> single != 0 ? T::append_scalar(label(l), &frs(p, 1)[0])
-    //                                                       : T::append_scalars(label(l), frs(p, k).iter())
-    //   append_commitment(u, l, xy, inf)    -> T::append_commitment(label(l), &commitment_from_limbs(xy, inf))
-    //   challenge_scalar(u, l, out)         -> *(out as *mut F) = T::challenge_scalar(label(l))
-    let _ = (commitment_from_limbs, label as fn(*const c_char) -> &'static str, frs::<F> as unsafe fn(*const u64, usize) -> &'static [F]);
+    let st = unsafe { &mut *(u as *mut CallbackState<'_, F, PC, T>) };
+    if st.panic.is_some() {
+        return;   // already failed: do nothing more, prove_gpu reports it
+    }
+    let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| body(st)));
+    if let Err(e) = r {
+        let st = unsafe { &mut *(u as *mut CallbackState<'_, F, PC, T>) };
+        st.panic = Some(e);
+    }
+}
+
+/// `T: TranscriptProtocol<F, PC::Commitment>` behind the four callbacks of `zkt_transcript_vtable`.  Rust closures cannot
+/// be `extern "C"`: each callback is a monomorphised function that recovers the state from `user`.
+pub fn vtable<F, PC, T>(state: &mut CallbackState<'_, F, PC, T>) -> ffi::ZktTranscriptVtable
+where
+    F: PrimeField,
+    PC: HomomorphicCommitment<F>,
+    T: TranscriptProtocol<F, PC::Commitment>,
+{
     ffi::ZktTranscriptVtable {
-        user: transcript as *mut T as *mut c_void,
+        user: state as *mut CallbackState<'_, F, PC, T> as *mut c_void,
         append_u64: cb_append_u64::<F, PC, T>,
         append_scalars: cb_append_scalars::<F, PC, T>,
         append_commitment: cb_append_commitment::<F, PC, T>,
@@ -47,17 +67,24 @@ where
     }
 }
 extern "C" fn cb_append_u64<F: PrimeField, PC: HomomorphicCommitment<F>, T: TranscriptProtocol<F, PC::Commitment>>(u: *mut c_void, l: *const c_char, v: u64) {
-    unsafe { &mut *(u as *mut T) }.append_u64(label(l), v)
+    guarded::<F, PC, T>(u, |st| st.transcript.append_u64(label(l), v))
 }
 extern "C" fn cb_append_scalars<F: PrimeField, PC: HomomorphicCommitment<F>, T: TranscriptProtocol<F, PC::Commitment>>(u: *mut c_void, l: *const c_char, p: *const u64, k: usize, single: c_int) {
-    let t = unsafe { &mut *(u as *mut T) };
-    if single != 0 { t.append_scalar(label(l), &unsafe { frs::<F>(p, 1) }[0]) } else { t.append_scalars(label(l), unsafe { frs::<F>(p, k) }.iter()) }
+    guarded::<F, PC, T>(u, |st| {
+        if single != 0 { st.transcript.append_scalar(label(l), &unsafe { frs::<F>(p, 1) }[0]) }
+        else { st.transcript.append_scalars(label(l), unsafe { frs::<F>(p, k) }.iter()) }
+    })
 }
-extern "C" fn cb_append_commitment<F: PrimeField, PC: HomomorphicCommitment<F>, T: TranscriptProtocol<F, PC::Commitment>>(_u: *mut c_void, _l: *const c_char, _xy: *const u64, _inf: c_int) {
-    unimplemented!("T::append_commitment(label(l), &commitment_from_limbs(xy, inf)): needs the concrete curve's GroupAffine::new")
+extern "C" fn cb_append_commitment<F: PrimeField, PC: HomomorphicCommitment<F>, T: TranscriptProtocol<F, PC::Commitment>>(u: *mut c_void, l: *const c_char, xy: *const u64, inf: c_int) {
+    guarded::<F, PC, T>(u, |st| {
+        let c = (st.commitment_from_limbs)(xy, inf);
+        st.transcript.append_commitment(label(l), &c)
+    })
 }
 extern "C" fn cb_challenge_scalar<F: PrimeField, PC: HomomorphicCommitment<F>, T: TranscriptProtocol<F, PC::Commitment>>(u: *mut c_void, l: *const c_char, out: *mut u64) {
-    unsafe { *(out as *mut F) = (&mut *(u as *mut T)).challenge_scalar(label(l)) }
+    // on a panic the output keeps the zero the library initialised it with; the library then fails with
+    // ZKT_ERR_EQUAL_CHALLENGES at the next distinctness check and prove_gpu re-raises the panic
+    guarded::<F, PC, T>(u, |st| unsafe { *(out as *mut F) = st.transcript.challenge_scalar(label(l)) })
 }
 
 /// What `prove` hands over: wire evaluations (or the composer's variables + indices), the lookup table in IndexSet
@@ -80,10 +107,15 @@ where
         blinders: blinders.as_ptr() as *const u64, wires_on_device: 0,
         variables: core::ptr::null(), n_vars: 0, w_l: core::ptr::null(), w_r: core::ptr::null(), w_o: core::ptr::null(),
     };
-    let vt = vtable::<F, PC, T>(transcript, commitment_from_limbs);
+    let mut state = CallbackState::<F, PC, T> { transcript, commitment_from_limbs, panic: None, _f: core::marker::PhantomData };
+    let vt = vtable::<F, PC, T>(&mut state);
     let mut bytes = vec![0u8; 1024];
     let mut len = 0usize;
-    with_ctx::<F, _>(|ctx| check(ctx, unsafe { ffi::zkt_prove_with(ctx, &inputs, &vt, bytes.as_mut_ptr(), bytes.len(), &mut len) }))?;
+    let rc = with_ctx::<F, _>(|ctx| check(ctx, unsafe { ffi::zkt_prove_with(ctx, &inputs, &vt, bytes.as_mut_ptr(), bytes.len(), &mut len) }));
+    if let Some(p) = state.panic.take() {
+        std::panic::resume_unwind(p);   // a transcript callback panicked: the panic continues here, on the Rust side
+    }
+    rc?;
     bytes.truncate(len);
     Ok(bytes)   // the caller: Proof::<F, D, PC>::deserialize(&bytes[..]) (proof.rs:98-155)
 }
