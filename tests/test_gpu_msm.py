@@ -1,4 +1,6 @@
 """GPU parity: the HIP KZG/G1 MSM (through the C-ABI) against the CPU oracle and golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 
@@ -192,7 +194,8 @@ def test_msm_full_size_2_20(cv, ctxs):
     ctx = ctxs[cv.name]
     n = 1 << 20
     ctx.srs_generate(0x5EED, n)
-    assert ctx.msm_info()["window_bits"] in (17, 18)
+    # the digit width the setup picks by itself: 17 on BN254, 19 on BLS12-381 (its additions cost 2.4 x as much: fewer, wider)
+    assert ctx.msm_info()["window_bits"] == (17 if cv.name == "bn254" else 19) or os.environ.get("ZKT_MSM_CBITS")
     srs = ctx.srs_download(0, n)
     rng = np.random.default_rng(2020)
     a = rand_fr(rng, n)
@@ -208,15 +211,16 @@ def test_msm_full_size_2_20(cv, ctxs):
     assert C.add(cv, pa, pb) == pab
 
 
-def test_msm_2_21_wide_pairs_with_compile_time_digits(ctxs):
+def test_msm_2_21_wide_pairs_and_wide_digits(ctxs):
     """BN254 at n = 2^21: the table index no longer fits a 4-byte pair (26 index bits), so the level-1 split writes
-    (key, value) pairs, while the window layout (15 x 17 bits) still takes the compile-time digit path -- the one
-    combination the prover's configs do not reach.  Canonical and Montgomery scalars, against the oracle."""
+    (key, value) pairs; from this size on the digits are 19 bits wide (14 windows, 2^18 buckets), which takes the
+    1024-column level-2 tables and the generic digit loop -- a combination the prover's configs do not reach.  Canonical and
+    Montgomery scalars, against the oracle."""
     cv = F.BN254
     ctx = ctxs[cv.name]
     n = 1 << 21
     ctx.srs_generate(0xA5A5, n)
-    assert ctx.msm_info()["windows"] == 15
+    assert (ctx.msm_info()["windows"], ctx.msm_info()["window_bits"]) == (14, 19) or os.environ.get("ZKT_MSM_CBITS")
     srs = ctx.srs_download(0, n)
     assert np.array_equal(srs[:32], K.srs_mont(cv, 0xA5A5, 32))          # the table's R^-1 scaling is undone on the way out
     rng = np.random.default_rng(21)

@@ -26,6 +26,7 @@
 #include "hostec.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -68,6 +69,7 @@ struct MsmState {
     uint32_t* chunk_bucket = nullptr;              // bucket of the first pair of every accumulation chunk
     uint32_t nb1 = 0;                              // level-1 bins
     uint32_t lb = 8;                               // level-2 key bits: bucket = (bin << lb) | low
+    int lcols = 8;                                 // log2 columns of the level-2 tables (8, or 10 for more than 2^17 buckets)
     bool packed = false;                           // (low key, table index, sign) fit ONE 32-bit word: 4-byte pairs
     int dig = 0;                                   // compile-time window layout of the level-1 kernels (0: generic)
     uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
@@ -232,10 +234,15 @@ ZKT_D void msm_for_each_digit(const Fe<R>& s, const MsmWindows& win, F&& emit) {
 template <int DIG> struct DigitLayout { static constexpr int LO = 0, REM = 0, W = 0; };
 template <> struct DigitLayout<1> { static constexpr int LO = 17, REM = 0, W = 15; };   // 255 bits = 15 x 17
 template <> struct DigitLayout<2> { static constexpr int LO = 17, REM = 1, W = 15; };   // 256 bits = 18 + 14 x 17
+template <> struct DigitLayout<3> { static constexpr int LO = 18, REM = 4, W = 14; };   // 256 bits = 4 x 19 + 10 x 18 (BLS12-381, n = 2^20)
+template <> struct DigitLayout<4> { static constexpr int LO = 19, REM = 9, W = 13; };   // 256 bits = 9 x 20 + 4 x 19 (BLS12-381, n = 2^22)
+constexpr int MSM_DIGIT_LAYOUTS = 4;
 static int msm_digit_layout(const MsmWindows& win, int total_bits) {
-    for (int dig = 1; dig <= 2; ++dig) {
-        const int lo = dig == 1 ? DigitLayout<1>::LO : DigitLayout<2>::LO, rem = dig == 1 ? DigitLayout<1>::REM : DigitLayout<2>::REM,
-                  W = dig == 1 ? DigitLayout<1>::W : DigitLayout<2>::W;
+    static const int los[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::LO, DigitLayout<2>::LO, DigitLayout<3>::LO, DigitLayout<4>::LO};
+    static const int rems[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::REM, DigitLayout<2>::REM, DigitLayout<3>::REM, DigitLayout<4>::REM};
+    static const int ws[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::W, DigitLayout<2>::W, DigitLayout<3>::W, DigitLayout<4>::W};
+    for (int dig = 1; dig <= MSM_DIGIT_LAYOUTS; ++dig) {
+        const int lo = los[dig], rem = rems[dig], W = ws[dig];
         if (win.W != W || W * lo + rem != total_bits) continue;
         bool ok = true;
         for (int w = 0; w < W; ++w) ok = ok && win.width[w] == lo + (w < rem ? 1 : 0);
@@ -281,7 +288,8 @@ ZKT_D void msm_for_each_digit_sel(const Fe<R>& s, const MsmWindows& win, F&& emi
 //            the last one writing only the table indices plus offsets[bucket].
 // Order inside a bucket is arbitrary, which is all the accumulation needs.  Zero digits are dropped.
 // ---------------------------------------------------------------------------------------------
-constexpr int MSM_BIN_LB_MAX = 8;         // level-2 key bits (at most: the level-2 tables have 256 columns)
+constexpr int MSM_BIN_LB_MAX = 8;         // level-2 key bits with 256-column level-2 tables (up to 2^17 buckets)
+constexpr int MSM_BIN_LB_WIDE = 10;       // ... with 1024-column tables (more buckets: wide pairs only)
 constexpr int MSM_L1_CAP = 15360;         // 8-byte pairs staged per level-1 workgroup (120 KB of LDS); twice as many 4-byte ones
 // Pair formats after the level-1 split.  When the table index (< W * count), the sign and `lb` low key bits fit 32 bits
 // the pair is ONE word: low key | index << lb | sign << 31 (n = 2^20: 24 index bits, lb = 7, 513 bins); the level-1
@@ -519,13 +527,17 @@ ZKT_D L2Item msm_l2_item(uint32_t item, uint32_t nb1, const uint32_t* tile_start
     return r;
 }
 
-template <class PF>
+// LC = log2 of the level-2 table's columns: 8 for up to 2^17 buckets (256 columns, lb <= 8), 10 beyond (1024 columns,
+// lb = 10: the digit widths c = 19, 20 that pay at n >= 2^22, where W n additions outweigh 2^(c-1) buckets to reduce).
+template <class PF, int LC>
 __global__ __launch_bounds__(256) void k_msm_l2_count(const typename PF::type* pairs, uint32_t nb1, uint32_t lb,
                                                       const uint32_t* tile_start, const uint2* tile_desc, uint32_t* cnt2) {
-    __shared__ uint32_t hist[256];
+    constexpr uint32_t COLS = 1u << LC;
+    __shared__ uint32_t hist[COLS];
     const L2Item it = msm_l2_item(blockIdx.x, nb1, tile_start, tile_desc);
     if (!it.valid) return;
-    hist[threadIdx.x] = 0;
+#pragma unroll
+    for (uint32_t c = threadIdx.x; c < COLS; c += 256) hist[c] = 0;
     __syncthreads();
     // eight independent loads per thread in flight before the first LDS atomic
     const uint32_t cnt = it.e - it.s;
@@ -543,62 +555,88 @@ __global__ __launch_bounds__(256) void k_msm_l2_count(const typename PF::type* p
         }
     }
     __syncthreads();
-    cnt2[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
+#pragma unroll
+    for (uint32_t c = threadIdx.x; c < COLS; c += 256) cnt2[(size_t)blockIdx.x * COLS + c] = hist[c];
 }
 
-// one workgroup per bin: positions of every (tile, bucket) run and offsets[bucket]
+// one workgroup per bin: positions of every (tile, bucket) run and offsets[bucket].  Thread t owns the K = COLS / 256
+// consecutive columns t K .. t K + K - 1.
+template <int LC>
 __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint32_t* pos2, const uint32_t* bin_start,
                                                      const uint32_t* tile_start, uint32_t* offsets, uint32_t B, uint32_t lb,
                                                      uint32_t chunk, uint32_t* chunk_bucket) {
+    constexpr uint32_t COLS = 1u << LC, K = COLS / 256u;
     const uint32_t b = blockIdx.x;
     const uint32_t t0 = tile_start[b], t1 = tile_start[b + 1];
-    uint32_t run = 0;
+    uint32_t run[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) run[k] = 0;
     for (uint32_t t = t0; t < t1; ++t) {
-        const size_t at = (size_t)t * 256 + threadIdx.x;
-        pos2[at] = run;
-        run += cnt2[at];
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) {
+            const size_t at = (size_t)t * COLS + threadIdx.x * K + k;
+            pos2[at] = run[k];
+            run[k] += cnt2[at];
+        }
     }
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) mine += run[k];
     __shared__ uint32_t wsum4[4];
-    const uint32_t first = bin_start[b] + block_excl_scan_256(run, wsum4);
-    // bucket = (bin << lb) | low; columns at or above 2^lb of the 256 never receive a pair and own no bucket
-    const bool owns = threadIdx.x < (1u << lb);
-    const uint32_t key = (b << lb) + threadIdx.x;
-    if (owns) offsets[key] = first;   // sized (nb1 << lb) + 2; keys above B are empty and repeat the end
+    uint32_t first[K];
+    first[0] = bin_start[b] + block_excl_scan_256(mine, wsum4);
+#pragma unroll
+    for (uint32_t k = 1; k < K; ++k) first[k] = first[k - 1] + run[k - 1];
     // accumulation chunk t starts at pair t * chunk: tell it which bucket that pair belongs to.  A bucket normally
     // covers a handful of chunks; a crowded one (skewed digits) is written by the whole workgroup.
     __shared__ uint32_t big[256][3];
     __shared__ uint32_t nbig;
     if (threadIdx.x == 0) nbig = 0;
     __syncthreads();
-    if (owns && key >= 1 && key <= B && run) {
-        const uint32_t tb = (first + chunk - 1) / chunk;
-        const uint32_t te = (uint32_t)(((uint64_t)first + run + chunk - 1) / chunk);   // one past the last chunk start inside
-        if (te - tb > 64) {
-            const uint32_t at = atomicAdd(&nbig, 1u);
-            big[at][0] = key; big[at][1] = tb; big[at][2] = te;
-        } else {
-            for (uint32_t t = tb; t < te; ++t) chunk_bucket[t] = key;
+#pragma unroll
+    for (uint32_t k = 0; k < K; ++k) {
+        // bucket = (bin << lb) | low; columns at or above 2^lb never receive a pair and own no bucket
+        const uint32_t col = threadIdx.x * K + k;
+        const bool owns = col < (1u << lb);
+        const uint32_t key = (b << lb) + col;
+        if (owns) offsets[key] = first[k];   // sized (nb1 << lb) + 2; keys above B are empty and repeat the end
+        if (owns && key >= 1 && key <= B && run[k]) {
+            const uint32_t tb = (first[k] + chunk - 1) / chunk;
+            const uint32_t te = (uint32_t)(((uint64_t)first[k] + run[k] + chunk - 1) / chunk);   // one past the last chunk start inside
+            uint32_t at = 256;
+            if (te - tb > 64) at = atomicAdd(&nbig, 1u);
+            if (at < 256) {
+                big[at][0] = key; big[at][1] = tb; big[at][2] = te;
+            } else {
+                for (uint32_t t = tb; t < te; ++t) chunk_bucket[t] = key;
+            }
         }
     }
     __syncthreads();
-    for (uint32_t e = 0; e < nbig; ++e)
+    const uint32_t nb = nbig < 256u ? nbig : 256u;
+    for (uint32_t e = 0; e < nb; ++e)
         for (uint32_t t = big[e][1] + threadIdx.x; t < big[e][2]; t += 256) chunk_bucket[t] = big[e][0];
-    for (uint32_t t = t0; t < t1; ++t) pos2[(size_t)t * 256 + threadIdx.x] += first;
+    for (uint32_t t = t0; t < t1; ++t) {
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) pos2[(size_t)t * COLS + threadIdx.x * K + k] += first[k];
+    }
 }
 
-// 1024 threads per 8192-pair tile: the 42 KB of LDS allow two such workgroups (32 waves) per CU, where 256-thread
-// workgroups left 12 waves to hide the latency this kernel consists of.  The pair loads are issued before the scan of
-// the 256 counters, so that they travel while it runs.
+// 1024 threads per 8192-pair tile: the 42 KB of LDS (56 KB with 1024 columns) allow two such workgroups (32 waves) per CU,
+// where 256-thread workgroups left 12 waves to hide the latency this kernel consists of.  The pair loads are issued before
+// the scan of the counters, so that they travel while it runs.
 constexpr int MSM_L2S_THREADS = 1024;
 constexpr int MSM_L2S_PER = MSM_L2_TILE / MSM_L2S_THREADS;   // pairs per thread
-template <class PF>
+template <class PF, int LC>
 __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typename PF::type* pairs, uint32_t nb1, uint32_t lb,
                                                                     const uint32_t* tile_start, const uint2* tile_desc,
                                                                     const uint32_t* cnt2, const uint32_t* pos2,
                                                                     uint32_t* vals) {
-    __shared__ uint32_t cursor[256], delta[256], wsum4[4];
+    constexpr uint32_t COLS = 1u << LC;
+    typedef typename std::conditional<(LC <= 8), uint8_t, uint16_t>::type key_t;
+    __shared__ uint32_t cursor[COLS], delta[COLS], wsum[16];
     __shared__ uint32_t sval[MSM_L2_TILE];
-    __shared__ uint8_t skey[MSM_L2_TILE];
+    __shared__ key_t skey[MSM_L2_TILE];
     const L2Item it = msm_l2_item(blockIdx.x, nb1, tile_start, tile_desc);
     if (!it.valid) return;
     const uint32_t cnt = it.e - it.s;
@@ -609,12 +647,14 @@ __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typena
         if (j < cnt) v[k] = pairs[it.s + j];
     }
     uint32_t mine = 0, p2 = 0;
-    if (threadIdx.x < 256) {
-        mine = cnt2[(size_t)blockIdx.x * 256 + threadIdx.x];
-        p2 = pos2[(size_t)blockIdx.x * 256 + threadIdx.x];
+    if (threadIdx.x < COLS) {
+        mine = cnt2[(size_t)blockIdx.x * COLS + threadIdx.x];
+        p2 = pos2[(size_t)blockIdx.x * COLS + threadIdx.x];
     }
-    const uint32_t ex = block_excl_scan_256(mine, wsum4);
-    if (threadIdx.x < 256) {
+    uint32_t ex;
+    if constexpr (LC <= 8) ex = block_excl_scan_256(mine, wsum);
+    else ex = block_excl_scan_1024(mine, wsum, nullptr);
+    if (threadIdx.x < COLS) {
         cursor[threadIdx.x] = ex;
         delta[threadIdx.x] = p2 - ex;
     }
@@ -630,7 +670,7 @@ __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typena
         const uint32_t j = (uint32_t)MSM_L2S_THREADS * k + threadIdx.x;
         if (j < cnt) {
             sval[a[k]] = PF::val(v[k], lb);
-            skey[a[k]] = (uint8_t)PF::low(v[k], lb);
+            skey[a[k]] = (key_t)PF::low(v[k], lb);
         }
     }
     __syncthreads();
@@ -859,6 +899,28 @@ __global__ void k_srs_to_fx(Affine<typename C::Fq>* table, size_t total) {
 // rows of partial sums an MSM leaves for the host besides the top bucket's: one per bit of the bucket index below B
 static int msm_rows(int c) { return c - 1; }
 
+// level-1 kernels by digit layout (0 = generic loop)
+template <class C>
+static auto msm_pick_bin_count(int dig) -> decltype(&k_msm_bin_count<C, 0>) {
+    switch (dig) {
+        case 1: return k_msm_bin_count<C, 1>;
+        case 2: return k_msm_bin_count<C, 2>;
+        case 3: return k_msm_bin_count<C, 3>;
+        case 4: return k_msm_bin_count<C, 4>;
+        default: return k_msm_bin_count<C, 0>;
+    }
+}
+template <class C, class PF>
+static auto msm_pick_bin_scatter(int dig) -> decltype(&k_msm_bin_scatter<C, PF, 0>) {
+    switch (dig) {
+        case 1: return k_msm_bin_scatter<C, PF, 1>;
+        case 2: return k_msm_bin_scatter<C, PF, 2>;
+        case 3: return k_msm_bin_scatter<C, PF, 3>;
+        case 4: return k_msm_bin_scatter<C, PF, 4>;
+        default: return k_msm_bin_scatter<C, PF, 0>;
+    }
+}
+
 static int floor_log2(size_t x) {
     int l = 0;
     while ((x >> (l + 1)) != 0) ++l;
@@ -871,10 +933,19 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     using R = typename C::Fr;
     auto st = std::make_shared<MsmState>();
     st->count = count;
+    // Digit width.  W n additions against 2^(c-1) buckets to reduce and a sort whose pairs stop fitting 32 bits beyond
+    // 2^17 buckets: measured on MI355X (profiles/ab_digit_width_r04.txt), BN254 n = 2^20 is best at c = 17 (wider digits
+    // give the accumulation 10 % and take it back in the grouping), BLS12-381 -- whose additions cost 2.4 x as much, the
+    // sort the same -- gains 4.6 % per proof from c = 19 at n = 2^20 and 7 % from c = 20 at n = 2^22.
     int lg = floor_log2(count ? count : 1);
     int cb = lg - 2;
     if (cb < 8) cb = 8;
-    if (cb > 18) cb = 18;
+    if (lg <= 20) {
+        if (cb > 18) cb = 18;
+        if (Q::N == 12 && lg == 20) cb = 19;
+    } else if (cb > 20) {
+        cb = 20;   // 2^19 buckets: the sort's limit (1024 level-1 bins x 1024 level-2 columns, wide pairs)
+    }
     if (const char* e = exp_env("ZKT_MSM_CBITS")) {   // experiment: another digit width (fewer windows, more buckets)
         const int f = atoi(e);
         if (f >= 8 && f <= MSM_MAX_Y) cb = f;
@@ -910,6 +981,10 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         if (lb > MSM_BIN_LB_MAX) lb = MSM_BIN_LB_MAX;
         st->packed = lb >= 4 && ((st->B >> lb) + 1) < (uint32_t)MSM_MAX_NB1;
         st->lb = st->packed ? (uint32_t)lb : (uint32_t)MSM_BIN_LB_MAX;
+        if (!st->packed && ((st->B >> st->lb) + 1) >= (uint32_t)MSM_MAX_NB1) {   // more than 2^17 buckets
+            st->lb = MSM_BIN_LB_WIDE;
+            st->lcols = MSM_BIN_LB_WIDE;
+        }
     }
     st->nb1 = (st->B >> st->lb) + 1;
     if (st->nb1 >= (uint32_t)MSM_MAX_NB1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm: too many level-1 bins");
@@ -925,14 +1000,13 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((rc = dev_alloc(c, (void**)&st->tile_start, ((size_t)st->nb1 + 1) * 4))) return rc;
     st->l2_items = (uint32_t)(m / MSM_L2_TILE + st->nb1);
     if ((rc = dev_alloc(c, &st->tile_desc, (size_t)st->l2_items * 8))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->cnt2, (size_t)st->l2_items * 256 * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->pos2, (size_t)st->l2_items * 256 * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->cnt2, ((size_t)st->l2_items << st->lcols) * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->pos2, ((size_t)st->l2_items << st->lcols) * 4))) return rc;
     {
         const int lds = (int)(((3 * st->nb1 + 3) & ~3u) * 4 + MSM_L1_CAP * (st->packed ? 4 : 8));
-        const void* fns[6] = {(const void*)k_msm_bin_scatter<C, PairPacked, 0>, (const void*)k_msm_bin_scatter<C, PairPacked, 1>,
-                              (const void*)k_msm_bin_scatter<C, PairPacked, 2>, (const void*)k_msm_bin_scatter<C, PairWide, 0>,
-                              (const void*)k_msm_bin_scatter<C, PairWide, 1>,   (const void*)k_msm_bin_scatter<C, PairWide, 2>};
-        for (const void* f : fns) ZKT_HIP(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const void* f = st->packed ? (const void*)msm_pick_bin_scatter<C, PairPacked>(st->dig)
+                                   : (const void*)msm_pick_bin_scatter<C, PairWide>(st->dig);
+        ZKT_HIP(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     static_assert(MsmState::SLOTS == 11, "per-slot arrays are sized for 11 slots");
     for (int i = 0; i < MsmState::SLOTS; ++i) {
@@ -1108,7 +1182,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         const unsigned nblk = (unsigned)((n + S - 1) / S);
         const uint32_t total = st.nb1 * nblk, ntiles = (total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
         {
-            auto kc = st.dig == 1 ? k_msm_bin_count<C, 1> : st.dig == 2 ? k_msm_bin_count<C, 2> : k_msm_bin_count<C, 0>;
+            auto kc = msm_pick_bin_count<C>(st.dig);
             hipLaunchKernelGGL(kc, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream, (const Fe<R>*)d_scalars, n, mont,
                                st.win, S, st.nb1, st.lb, st.bin_offs);
         }
@@ -1119,30 +1193,34 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         const size_t lds_scatter = (size_t)((3 * st.nb1 + 3) & ~3u) * 4 + (size_t)MSM_L1_CAP * (st.packed ? 4 : 8);
         const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
         if (st.packed) {
-            auto ks = st.dig == 1 ? k_msm_bin_scatter<C, PairPacked, 1> : st.dig == 2 ? k_msm_bin_scatter<C, PairPacked, 2>
-                                                                                          : k_msm_bin_scatter<C, PairPacked, 0>;
+            auto ks = msm_pick_bin_scatter<C, PairPacked>(st.dig);
             hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
                                st.count, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
-            hipLaunchKernelGGL(k_msm_l2_count<PairPacked>, dim3(items), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
+            hipLaunchKernelGGL((k_msm_l2_count<PairPacked, 8>), dim3(items), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
                                st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
         } else {
-            auto ks = st.dig == 1 ? k_msm_bin_scatter<C, PairWide, 1> : st.dig == 2 ? k_msm_bin_scatter<C, PairWide, 2>
-                                                                                          : k_msm_bin_scatter<C, PairWide, 0>;
+            auto ks = msm_pick_bin_scatter<C, PairWide>(st.dig);
             hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
                                st.count, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
-            hipLaunchKernelGGL(k_msm_l2_count<PairWide>, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+            auto kc2 = st.lcols == 8 ? k_msm_l2_count<PairWide, 8> : k_msm_l2_count<PairWide, 10>;
+            hipLaunchKernelGGL(kc2, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
                                st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
         }
-        hipLaunchKernelGGL(k_msm_l2_scan, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
-                           st.tile_start, st.offsets[slot], st.B, st.lb, chunk, st.chunk_bucket);
-        if (st.packed)
-            hipLaunchKernelGGL(k_msm_l2_scatter<PairPacked>, dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint32_t*)st.pairs,
+        {
+            auto ksc = st.lcols == 8 ? k_msm_l2_scan<8> : k_msm_l2_scan<10>;
+            hipLaunchKernelGGL(ksc, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
+                               st.tile_start, st.offsets[slot], st.B, st.lb, chunk, st.chunk_bucket);
+        }
+        if (st.packed) {
+            hipLaunchKernelGGL((k_msm_l2_scatter<PairPacked, 8>), dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint32_t*)st.pairs,
                                st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2);
-        else
-            hipLaunchKernelGGL(k_msm_l2_scatter<PairWide>, dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+        } else {
+            auto kss = st.lcols == 8 ? k_msm_l2_scatter<PairWide, 8> : k_msm_l2_scatter<PairWide, 10>;
+            hipLaunchKernelGGL(kss, dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint2*)st.pairs, st.nb1,
                                st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2);
+        }
         ZKT_HIP(c, hipGetLastError());
     }
     {
