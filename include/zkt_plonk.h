@@ -330,6 +330,8 @@ typedef struct {
     const uint32_t* d_trace_base;   /* per hash, or NULL */
     size_t trace_base0;
     void* d_out_hashes;             /* optional: batch scalars */
+    int kernel;                     /* 0: chosen by batch size; 1: one thread per hash (throughput: large batches);
+                                     * 2: width^2 lanes per hash (latency: a single proof's few hundred hashes) */
 } zkt_poseidon_gadget_args;
 size_t zkt_poseidon_gadget_vars_per_hash(const zkt_poseidon* params);
 int zkt_poseidon_gadget_witness_dev(zkt_ctx* ctx, const zkt_poseidon* params, const zkt_poseidon_gadget_args* args);

@@ -108,6 +108,7 @@ pub struct ZktPoseidonGadgetArgs {
     pub d_trace_base: *const u32,
     pub trace_base0: usize,
     pub d_out_hashes: *mut c_void,
+    pub kernel: c_int,
 }
 
 #[repr(C)]

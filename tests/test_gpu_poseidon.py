@@ -142,13 +142,16 @@ def _load(ctx, cv, prm):
                              K.fr_to_mont(cv, [x for row in prm.mds for x in row]), K.fr_to_mont(cv, [prm.domain_tag])[0])
 
 
-@pytest.mark.parametrize("cvname,w", [("bn254", 3), ("bn254", 4), ("bn254", 5), ("bls12_381", 2), ("bls12_381", 5), ("bls12_381", 8)])
-def test_gadget_witness_equals_the_composers_variables(cvname, w):
+@pytest.mark.parametrize("kernel", [1, 2], ids=["thread_per_hash", "lanes_per_hash"])
+@pytest.mark.parametrize("cvname,w", [("bn254", 3), ("bn254", 4), ("bn254", 5), ("bls12_381", 2), ("bls12_381", 5), ("bls12_381", 8),
+                                      ("bls12_381", 6)])
+def test_gadget_witness_equals_the_composers_variables(cvname, w, kernel):
     """k_poseidon_gadget against the oracle's gate-by-gate restatement of PlonkSpecRef on the composer
     (oracle/composer.py: spec.rs:174-219 on constraint_system/arithmetic.rs:15-104): for every hash the
     2 half_full (3W + W^2) + partial (3 + W^2) values the composer assigns, in its allocation order -- 804 / 1288 / 1888
     on the reference's x3 / x4 / x5 -- for arities 0, 1 and W - 1, inputs given as values and as variable indices
-    (Variable::Zero included), dense and scattered trace bases."""
+    (Variable::Zero included), dense and scattered trace bases.  Both kernels: one thread per hash (large batches) and
+    W^2 lanes per hash (a single proof's hashes: four dependent products per round instead of 28 - 40)."""
     import zkt_plonk_amd as z
     import zkt_plonk_amd._lib as L
     from oracle import composer as OC
@@ -173,7 +176,7 @@ def test_gadget_witness_equals_the_composers_variables(cvname, w):
         if arity:
             ctx.upload(d_in, K.fr_to_mont(cv, [x for row in ins for x in row]))
         ctx.poseidon_gadget_witness_dev(h, batch, arity, d_vars, n_vars, d_inputs=d_in if arity else 0, trace_base0=5,
-                                        d_out_hashes=d_out)
+                                        d_out_hashes=d_out, kernel=kernel)
         ctx.poseidon_gadget_check(h)
         got = K.fr_from_mont(cv, ctx.download(d_vars, (n_vars, 4)))
         hashes = K.fr_from_mont(cv, ctx.download(d_out, (batch, 4)))
@@ -200,7 +203,7 @@ def test_gadget_witness_equals_the_composers_variables(cvname, w):
             ctx.upload(d_v2, np.concatenate([K.fr_to_mont(cv, vals), np.zeros((n_vars - len(vals), 4), np.uint64)]))
             ctx.upload(d_idx, idx)
             ctx.upload(d_base, bases)
-            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base)
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base, kernel=kernel)
             ctx.poseidon_gadget_check(h)
             got2 = K.fr_from_mont(cv, ctx.download(d_v2, (n_vars, 4)))
             assert got2[:batch * arity] == vals
@@ -211,15 +214,17 @@ def test_gadget_witness_equals_the_composers_variables(cvname, w):
             # an index outside the map: that hash is skipped, the flag is raised once and cleared
             bases[7] = n_vars - per + 1
             ctx.upload(d_base, bases)
-            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base)
+            before = ctx.download(d_v2, (n_vars, 4))
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base, kernel=kernel)
             with pytest.raises(L.ZktError):
                 ctx.poseidon_gadget_check(h)
             ctx.poseidon_gadget_check(h)
+            assert np.array_equal(ctx.download(d_v2, (n_vars, 4)), before)      # the skipped hash wrote nothing, the others the same
             idx[9, arity - 1] = n_vars
             bases[7] = 0
             ctx.upload(d_base, bases)
             ctx.upload(d_idx, idx)
-            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base)
+            ctx.poseidon_gadget_witness_dev(h, batch, arity, d_v2, n_vars, d_input_vars=d_idx, d_trace_base=d_base, kernel=kernel)
             with pytest.raises(L.ZktError):
                 ctx.poseidon_gadget_check(h)
             for d in (d_v2, d_idx, d_base):

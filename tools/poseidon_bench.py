@@ -39,6 +39,23 @@ for w, partial in ((3, 55), (4, 56), (5, 56)):
         print("x%d (Rf 8, Rp %d) %-14s %8.3f ms  %10.3e hashes/s  %9.3e field products/s%s" % (
             w, partial, "with states" if states else "hashes only", dt * 1e3, batch / dt, batch * muls / dt,
             "  (%.1f GB of states written)" % (batch * (rounds + 1) * w * 32 / 1e9) if states else ""))
+    # the gadget's witness (zkt_poseidon_gadget_witness_dev): vars_per_hash variables per hash, 32 B each
+    per = ctx.poseidon_gadget_vars_per_hash(h)
+    for kname, kernel, gb in (("one thread per hash", 1, 1 << 16), ("one thread per hash", 1, 538), ("W^2 lanes per hash", 2, 538),
+                              ("W^2 lanes per hash", 2, 1 << 14)):
+        d_vars = ctx.alloc(gb * per * 32)
+        run = lambda: ctx.poseidon_gadget_witness_dev(h, gb, w - 1, d_vars, gb * per, d_inputs=d_in, kernel=kernel)
+        run()
+        ctx.synchronize()
+        t = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            run()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t) / reps
+        print("x%d gadget witness, %-20s batch %6d: %8.3f ms  %10.3e hashes/s  %9.3e products/s  %6.1f GB/s of variables written" % (
+            w, kname, gb, dt * 1e3, gb / dt, gb * per / dt, gb * per * 32 / dt / 1e9))
+        ctx.free(d_vars)
     ctx.poseidon_free(h)
     for d in (d_in, d_out, d_st):
         ctx.free(d)

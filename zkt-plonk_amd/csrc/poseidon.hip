@@ -236,6 +236,113 @@ __global__ __launch_bounds__(128) void k_poseidon_gadget(PoseidonGadgetArgs<P> a
     if (a.out) fe_store<P>(a.out + h, fx_pack<P>(st[1]));   // spec.rs:315: elements[1]
 }
 
+
+// ---- the same witness with W^2 lanes per hash (small batches) --------------------------------------------------------
+// One thread per hash walks a dependency chain of 3W + W^2 (full) / 3 + W^2 (partial) products per round: a single
+// proof's few hundred hashes (538 in the withdraw circuit at n = 2^20) then take as long as that chain, ~1.7 ms per launch,
+// whatever the size of the chip.  Here a hash is spread over LPH >= W^2 lanes of one wavefront: lane (j, i) = j W + i
+// holds element i of the state, every lane runs the s-box of its element (three dependent products, redundantly across
+// j), multiplies by its own matrix entry m[i][j] (kept in registers for the whole permutation), and the W^2 running sums
+// of product_mds are an inclusive scan over i inside each segment j (log2 W shuffle steps).  Depth per round: four products
+// instead of 28 - 40, and a round's W^2 sums leave as consecutive 32-byte stores.  Throughput per hash is ~4 x worse than
+// k_poseidon_gadget's (lanes idle or redundant in the s-box phase): the host picks this kernel for batches that cannot
+// fill the chip with one thread per hash (POSEIDON_LANES_MAX_BATCH).
+constexpr uint64_t POSEIDON_LANES_MAX_BATCH = 16384;
+
+template <int W>
+struct PoseidonLanes {
+    static constexpr int LPH = W * W <= 4 ? 4 : W * W <= 16 ? 16 : W * W <= 32 ? 32 : 64;   // lanes per hash
+    static constexpr int PER_WAVE = 64 / LPH;
+};
+
+template <class P>
+ZKT_D Fx<P> fx_shfl(const Fx<P>& a, int src_lane) {
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = (uint32_t)__shfl((int)a.l[i], src_lane);
+    return r;
+}
+
+template <class P, int W>
+__global__ __launch_bounds__(256) void k_poseidon_gadget_lanes(PoseidonGadgetArgs<P> a) {
+    static_assert(FxP<P>::L == 9 && FxP<P>::SH == 5, "scalar fields: nine limbs, R' = 32 R");
+    constexpr int LPH = PoseidonLanes<W>::LPH, PER_WAVE = PoseidonLanes<W>::PER_WAVE;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPH;                 // which hash of this wavefront
+    const int l = lane % LPH;                   // lane inside the hash
+    const int seg0 = lane - l;                  // first lane of the hash
+    const bool live = l < W * W;
+    const int i = live ? l % W : 0, j = live ? l / W : 0;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t h = wave * PER_WAVE + sub;
+    const bool have = h < a.batch;              // lanes without a hash run along (shuffles are wave-wide) and store nothing
+    const uint64_t hh = have ? h : 0;
+    const int rounds = 2 * a.half_full + a.partial;
+    const uint64_t per_hash = (uint64_t)2 * a.half_full * (3 * W + W * W) + (uint64_t)a.partial * (3 + W * W);
+    const uint64_t base = a.trace_base ? (uint64_t)a.trace_base[hh] : a.base0 + hh * per_hash;
+    bool ok = base <= a.n_vars && per_hash <= a.n_vars - base;
+    // element i of the initial state (spec.rs:239-263)
+    Fx<P> x = fx_zero<P>();
+    if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < FxP<P>::L; ++k) x.l[k] = a.tag_a[k];
+    } else if (i - 1 < a.arity) {
+        if (a.input_vars) {
+            const uint32_t v = a.input_vars[hh * a.arity + (i - 1)];
+            if (v != ZKT_VARIABLE_ZERO) {
+                if (v < a.n_vars) x = fx_unpack<P>(fe_load<P>(a.vars + v));
+                else ok = false;
+            }
+        } else {
+            x = fx_unpack<P>(fe_load<P>(a.inputs + hh * a.arity + (i - 1)));
+        }
+    }
+    // a hash is skipped as a whole: every lane of it must agree
+    const unsigned long long bad = __ballot(have && live && !ok);
+    const unsigned long long mine = (LPH == 64) ? ~0ull : (((1ull << LPH) - 1ull) << seg0);
+    const bool run = have && (bad & mine) == 0;
+    if (have && l == 0 && !run) atomicOr(a.status, 1u);
+    const Fx<P> m = fx_load_limbs<P>(a.mds + 9 * (i * W + j));    // my matrix entry, H form, for every round
+    Fe<P>* out = a.vars + base;
+    const uint32_t* rc = a.rc_a + 9 * i;
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const bool full = r < a.half_full || r >= a.half_full + a.partial;
+        x = fx_cond_sub_p<P>(fx_add<P>(x, fx_load_limbs<P>(rc)));     // add_constant: no gate
+        rc += 9 * W;
+        // power_of_5 of my element; kept where the round has an s-box for it
+        const Fx<P> xs = fx_shl_sh<P>(x);
+        const Fx<P> x2 = gadget_mul<P>(x, xs);
+        const Fx<P> x4 = gadget_mul<P>(x2, fx_shl_sh<P>(x2));
+        const Fx<P> x5 = gadget_mul<P>(x4, xs);
+        const bool boxed = full || i == 0;
+        if (run && live && j == 0 && boxed) {
+            Fe<P>* o = out + 3 * i;
+            fe_store<P>(o, fx_pack<P>(x2));
+            fe_store<P>(o + 1, fx_pack<P>(x4));
+            fe_store<P>(o + 2, fx_pack<P>(x5));
+        }
+        out += full ? 3 * W : 3;
+        Fx<P> s;
+#pragma unroll
+        for (int k = 0; k < FxP<P>::L; ++k) s.l[k] = boxed ? x5.l[k] : x.l[k];
+        // product_mds: my term, then the running sums over i inside segment j (inclusive scan, log2 W steps)
+        Fx<P> t = fx_cond_sub_p<P>(fx_mul<P>(s, m));
+#pragma unroll
+        for (int d = 1; d < W; d <<= 1) {
+            const Fx<P> o = fx_shfl<P>(t, lane - d);      // lane - d >= 0 whenever it is used (i >= d)
+            if (i >= d) t = fx_cond_sub_p<P>(fx_add<P>(t, o));
+        }
+        if (run && live) fe_store<P>(out + l, fx_pack<P>(t));
+        out += W * W;
+        // next state: element i = the last running sum of segment i
+        x = fx_shfl<P>(t, seg0 + i * W + (W - 1));
+    }
+    if (a.out && run && l == 1 % W) {   // spec.rs:315: elements[1] (W >= 2: lane 1 holds element 1)
+        fe_store<P>(a.out + h, fx_pack<P>(x));
+    }
+}
+
 }  // namespace zkt
 
 // the opaque handle of include/zkt_plonk.h: PoseidonConstants resident in HBM
@@ -336,8 +443,15 @@ static int poseidon_enqueue_t(zkt_ctx* c, const zkt_poseidon* h, const void* d_i
 }
 
 template <class P, int W>
-static void poseidon_gadget_launch_w(zkt_ctx* c, const PoseidonGadgetArgs<P>& a) {
-    hipLaunchKernelGGL((k_poseidon_gadget<P, W>), dim3((unsigned)((a.batch + 127) / 128)), dim3(128), 0, c->stream, a);
+static void poseidon_gadget_launch_w(zkt_ctx* c, const PoseidonGadgetArgs<P>& a, int mode) {
+    const bool lanes = mode == 2 || (mode == 0 && a.batch <= POSEIDON_LANES_MAX_BATCH);
+    if (lanes) {
+        constexpr uint64_t per_block = 4 * PoseidonLanes<W>::PER_WAVE;    // 256 threads = 4 wavefronts
+        hipLaunchKernelGGL((k_poseidon_gadget_lanes<P, W>), dim3((unsigned)((a.batch + per_block - 1) / per_block)), dim3(256), 0,
+                           c->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_poseidon_gadget<P, W>), dim3((unsigned)((a.batch + 127) / 128)), dim3(128), 0, c->stream, a);
+    }
 }
 
 template <class P>
@@ -358,14 +472,15 @@ static int poseidon_gadget_enqueue_t(zkt_ctx* c, const zkt_poseidon* h, const zk
     a.half_full = h->half_full;
     a.partial = h->partial;
     a.arity = g.arity;
+    const int mode = g.kernel;   // 0: by batch size; 1: one thread per hash; 2: W^2 lanes per hash
     switch (h->width) {
-        case 2: poseidon_gadget_launch_w<P, 2>(c, a); break;
-        case 3: poseidon_gadget_launch_w<P, 3>(c, a); break;
-        case 4: poseidon_gadget_launch_w<P, 4>(c, a); break;
-        case 5: poseidon_gadget_launch_w<P, 5>(c, a); break;
-        case 6: poseidon_gadget_launch_w<P, 6>(c, a); break;
-        case 7: poseidon_gadget_launch_w<P, 7>(c, a); break;
-        default: poseidon_gadget_launch_w<P, 8>(c, a); break;
+        case 2: poseidon_gadget_launch_w<P, 2>(c, a, mode); break;
+        case 3: poseidon_gadget_launch_w<P, 3>(c, a, mode); break;
+        case 4: poseidon_gadget_launch_w<P, 4>(c, a, mode); break;
+        case 5: poseidon_gadget_launch_w<P, 5>(c, a, mode); break;
+        case 6: poseidon_gadget_launch_w<P, 6>(c, a, mode); break;
+        case 7: poseidon_gadget_launch_w<P, 7>(c, a, mode); break;
+        default: poseidon_gadget_launch_w<P, 8>(c, a, mode); break;
     }
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
@@ -448,6 +563,7 @@ int zkt_poseidon_gadget_witness_dev(zkt_ctx* c, const zkt_poseidon* h, const zkt
     if (g->arity && !g->d_inputs == !g->d_input_vars)
         return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: exactly one of d_inputs / d_input_vars");
     if (g->n_vars > 0xFFFFFFFFull) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "variable indices are 32 bits wide");
+    if (g->kernel < 0 || g->kernel > 2) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: kernel = 0 (auto), 1 or 2");
     const size_t per = zkt_poseidon_gadget_vars_per_hash(h);
     if (!g->d_trace_base && (g->trace_base0 > g->n_vars || g->batch > (g->n_vars - g->trace_base0) / per))
         return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: the traces do not fit the variable map");
