@@ -396,3 +396,60 @@ def test_config0_the_withdraw_circuit_itself_at_2_14():
     ctx.free(d_vars)
     g.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("cvname,width,inputs,height,log_n", [("bn254", 4, 3, 48, 18), ("bls12_381", 5, 1, 3, 14)],
+                         ids=["bn254-cli-default-2^18", "bls12_381-2^14"])
+def test_withdraw_circuit_at_the_clis_default_size(cvname, width, inputs, height, log_n):
+    """The circuit the reference's binary builds with its DEFAULT features (bin/Cargo.toml:25: bn254, height-48, notes-3,
+    poseidon-bn254-x4: 200 793 gates, n = 2^18, 7 public inputs), and a BLS12-381 instance of the same circuit (generated
+    Poseidon constants: the reference ships BN254 tables only; width 5, one note, HEIGHT 3: n = 2^14).  Synthesised by the
+    oracle composer; the hashes' variables (155 x 1288 on BN254) come from the device in one launch per dependency level,
+    through zkt_plonk_amd.PoseidonGadget; proof bytes == the CPU oracle's array prover; the oracle's verifier accepts with
+    the CLI's public inputs and rejects a wrong root."""
+    import sys, os
+    import zkt_plonk_amd as z
+    from oracle import composer as OC, fastplonk as FP
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import withdraw_workload as WW
+    cv = F.CURVES[cvname]
+    p = cv.fr.p
+    if cvname == "bn254":
+        prm = _gadget_params(cv, width)
+    else:
+        hs = WW.synthetic_hasher(p, width)
+        prm = OC.PoseidonParams(p, width, hs.half_full, hs.partial, hs.rc, hs.mds, hs.tag)
+    cs, public_inputs = OC.withdraw_instance(cv, prm, inputs=inputs, height=height, seed=18)
+    assert cs.n_gates == OC.withdraw_gate_count(prm, inputs, height) and cs.check_satisfied()
+    n = cs.circuit_bound()
+    assert n == 1 << log_n and len(public_inputs) == 4 + inputs
+    tau = 0x5EED5EED1234567890ABCDEF % p
+    ctx = z.Context(cv.name, 0)
+    ctx.srs_generate(tau, n + 8)
+    srs = ctx.srs_download(0, n + 8)
+    be = K.CBackend(cv, srs)
+    evals = {k: K.fr_to_mont(cv, v) for k, v in P.setup_evals(be, cs).items()}
+    keys = FP.setup(cv, srs, log_n, evals, commitments=False)
+    prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+    L = cv.fq.limbs64
+    rinv = pow(1 << (64 * L), -1, cv.fq.p)
+    keys.commits = {name: (None if inf else (sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % cv.fq.p,
+                                             sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % cv.fq.p))
+                    for name, (xy, inf) in commits.items()}
+    assert FP.commit(cv, srs, keys.pk["q_m"]) == keys.commits["q_m"] and FP.commit(cv, srs, keys.pk["sigma2"]) == keys.commits["sigma2"]
+    vk = keys.verifier_key(cv, cs.pi.keys())
+    a, b, c = cs.wire_evals(cs.n_gates)
+    blinders = field_elems(p, 1800 + log_n, P.NUM_BLINDERS)
+    want = FP.prove(cv, srs, keys, K.fr_to_mont(cv, a), K.fr_to_mont(cv, b), K.fr_to_mont(cv, c), K.fr_to_mont(cv, cs.table),
+                    dict(cs.pi), P.new_seeded_transcript(cv, vk), blinders)
+    g = _gadget(z, ctx, cv, prm)
+    d_vars = _device_witness(ctx, cv, cs, g)
+    assert [len(x) for x in g.levels()] == [inputs * (2 + height) + 1, inputs + 1]
+    assert K.fr_from_mont(cv, ctx.download(d_vars, (len(cs.values), 4))) == cs.values
+    got = _prove_from_device_witness(ctx, cv, cs, d_vars, blinders, vk.n, vk.commits)
+    assert got == want and len(got) == (802 if cvname == "bn254" else 1010)
+    assert P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), public_inputs)
+    assert not P.verify(cv, tau, vk, P.proof_deserialize(cv, got), P.new_seeded_transcript(cv, vk), [public_inputs[0] + 1] + public_inputs[1:])
+    ctx.free(d_vars)
+    g.close()
+    ctx.close()
