@@ -1,4 +1,5 @@
-"""Experiment: throughput with F proofs in flight on one GPU (F independent contexts driven by F host threads)."""
+"""Experiment: throughput with F proofs in flight on one GPU (F independent contexts driven by F host threads).
+usage: python tools/inflight_bench.py F steps [shared|own] [log_n]"""
 import sys, os, time, threading, random
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -10,7 +11,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 shared = len(sys.argv) > 3 and sys.argv[3] == "shared"   # all contexts enqueue on ONE stream: kernels never overlap
 shared_stream = None
-log_n = 20
+log_n = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 fld = B.FIELDS["bn254"]
 n = 1 << log_n
 dev = torch.device("cuda", 0)
@@ -61,5 +62,5 @@ for x in th: x.join()
 torch.cuda.synchronize()
 el = time.perf_counter() - t
 total = (steps // F) * F
-print(("shared-stream " if shared else "") + "inflight=%d: %d proofs in %.3f s -> %.2f proofs/s (%.2f ms/proof); proofs identical: %s" % (
-    F, total, el, total / el, 1e3 * el / total, all(p == proofs[0] for p in proofs)), flush=True)
+print(("shared-stream " if shared else "") + "n=2^%d inflight=%d: %d proofs in %.3f s -> %.2f proofs/s (%.2f ms/proof); proofs identical: %s" % (
+    log_n, F, total, el, total / el, 1e3 * el / total, all(p == proofs[0] for p in proofs)), flush=True)

@@ -41,7 +41,7 @@ for w, partial in ((3, 55), (4, 56), (5, 56)):
             "  (%.1f GB of states written)" % (batch * (rounds + 1) * w * 32 / 1e9) if states else ""))
     # the gadget's witness (zkt_poseidon_gadget_witness_dev): vars_per_hash variables per hash, 32 B each
     per = ctx.poseidon_gadget_vars_per_hash(h)
-    for kname, kernel, gb in (("one thread per hash", 1, 1 << 16), ("one thread per hash", 1, 538), ("W^2 lanes per hash", 2, 538),
+    for kname, kernel, gb in (("one thread per hash", 1, 1 << 18), ("one thread per hash", 1, 538), ("W^2 lanes per hash", 2, 538),
                               ("W^2 lanes per hash", 2, 1 << 14)):
         d_vars = ctx.alloc(gb * per * 32)
         run = lambda: ctx.poseidon_gadget_witness_dev(h, gb, w - 1, d_vars, gb * per, d_inputs=d_in, kernel=kernel)
