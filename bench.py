@@ -233,10 +233,11 @@ def withdraw_workload(z, torch, ctx, dev, fld, args, log_n):
     witness = {"hashes": len(L0.hash_calls), "vars_per_hash": hs.per_hash, "variables": n_vars, "host_made_variables": n_host,
                "device_made_variables": n_vars - n_host, "device_ms": round(min(dev_ms), 3),
                "launches": len(gadget._staged), "hashes_per_launch": [c for _, c, _, _ in gadget._staged],
-               "is": "k_poseidon_gadget: every variable the PlonkSpecRef gadget allocates (x^2, x^4, x^5 per s-box, the W^2 "
-                     "running MDS sums per round) for all the circuit's hashes, written into the variable map in HBM; one "
-                     "thread per hash, so a single proof's %d hashes are latency-bound (a proving service batches the hashes "
-                     "of its queue); wall clock incl. launch, min of 5; outside the timed region" % len(L0.hash_calls)}
+               "is": "zkt_poseidon_gadget_witness_dev: every variable the PlonkSpecRef gadget allocates (x^2, x^4, x^5 per s-box, the W^2 "
+                     "running MDS sums per round) for all the circuit's %d hashes, written into the variable map in HBM; W^2 lanes per "
+                     "hash (k_poseidon_gadget_lanes: the batch is far too small for one thread per hash), one launch per dependency "
+                     "level (the leaf hashes take a commitment hash); wall clock incl. launches, min of 5; outside the timed region, as "
+                     "circuit.synthesize is outside proof_system::prove" % len(L0.hash_calls)}
     return dict(evals=evals, commits=commits, gates=gates, table=table, host_w=host_w, preps=preps, pis=pis,
                 pi_map0=dict(L0.pi), keep=(keep, d_idx, gadget), witness=witness, oracle_twin=(hs, insts[0]),
                 describe="full prove, WithdrawCircuit INPUTS=%d HEIGHT=%d Poseidon x%d (%d gates, %d Poseidon gadgets), %s, n=2^%d, "
