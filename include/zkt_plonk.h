@@ -86,10 +86,12 @@ const char* zkt_version(void);
  *     of 4n x 32 B in total brings the quotient evaluations together before the inverse transform.
  * Everything else (the n-point inverse transforms, grand products, evaluations, openings' polynomials, Fiat-Shamir) is
  * replicated: every rank produces the same proof bytes, equal to the single-GPU bytes.
- * The communicator is supplied by the caller (torch.distributed over RCCL in zkt-plonk_amd/parallel.py; any other
- * transport in a Rust host; the device branch of that Python transport -- an in-place all-gather on the library's own HBM
- * buffer -- has only ever run with a world of one: no multi-GPU node was available, it is UNVERIFIED ON HARDWARE; the
- * sharded prover itself is byte-checked with thread and gloo ranks on one GPU up to BLS12-381 n = 2^22 x 8 ranks).
+ * The communicator is supplied by the caller: libzkt_comm_rccl.so (zkt_comm_rccl.h) is that communicator over RCCL as a C
+ * library of its own, for hosts that have none (a Rust binary); zkt-plonk_amd/parallel.py has the same over
+ * torch.distributed.  This library links no transport.  With more than one GPU the device exchange -- an in-place
+ * all-gather on the library's own HBM buffer -- is UNVERIFIED ON HARDWARE: no multi-GPU node was available; it runs with
+ * world-of-one RCCL communicators under 2 / 4 thread-ranks on one GPU, and the sharded prover itself is byte-checked with
+ * thread and gloo ranks on one GPU up to BLS12-381 n = 2^22 x 8 ranks.
  * all_gather: `bytes` per rank, results in rank order; on_device = 0: host pointers;
  * on_device = 1 (only if device_buffers != 0): device pointers, the library has synchronised `hip_stream` before the
  * call and the exchange must be complete when the callback returns.  Returns 0 on success. */
