@@ -162,15 +162,29 @@ ZKT_D Fx<P> gadget_mul(const Fx<P>& a, const Fx<P>& b_shifted) {
     return fx_cond_sub_p<P>(fx_mul<P>(a, b_shifted));
 }
 
+// Stores.  A thread's variables are consecutive in memory, the 64 threads of a wavefront are vars_per_hash x 32 B apart:
+// written directly, every store instruction touches 64 different cache lines with 16 bytes each, and the kernel is bound by
+// the request rate of that (r04 first version: 1.5-1.7 TB/s of variables, half the issue rate of its own instruction stream).
+// So a wavefront stages GADGET_STAGE variables per hash in LDS ([k][lane]: conflict-free writes) and flushes them so that
+// 2 GADGET_STAGE consecutive lanes write one hash's GADGET_STAGE x 32 contiguous bytes (two full 128-byte lines at 8):
+// 2.4 TB/s on x3 / x4 / x5 alike (4 gives 2.6 / 2.6 / 2.1; profiles/poseidon_r04_v2.txt).
+constexpr int GADGET_STAGE = 8;
+
 template <class P, int W>
 __global__ __launch_bounds__(128) void k_poseidon_gadget(PoseidonGadgetArgs<P> a) {
     static_assert(FxP<P>::L == 9 && FxP<P>::SH == 5, "scalar fields: nine limbs, R' = 32 R");
     static_assert(P::BITS + FxP<P>::SH < 29 * FxP<P>::L, "p * 2^SH * p < R' p");
+    static_assert(sizeof(Fe<P>) == 32, "a variable is two 16-byte words");
+    constexpr int K = GADGET_STAGE;
+    __shared__ uint4 stage[2][K * 64 * 2];       // per wavefront: [k][lane] x two 16-byte halves
+    __shared__ uint64_t sbase[2][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= a.batch) return;
+    const bool have = h < a.batch;
+    const uint64_t hh = have ? h : 0;            // lanes without a hash run along (barriers below) and write nothing
     const int rounds = 2 * a.half_full + a.partial;
     const uint64_t per_hash = (uint64_t)2 * a.half_full * (3 * W + W * W) + (uint64_t)a.partial * (3 + W * W);
-    const uint64_t base = a.trace_base ? (uint64_t)a.trace_base[h] : a.base0 + h * per_hash;
+    const uint64_t base = a.trace_base ? (uint64_t)a.trace_base[hh] : a.base0 + hh * per_hash;
     bool ok = base <= a.n_vars && per_hash <= a.n_vars - base;
     Fx<P> st[W], nx[W];
     // reset + input (spec.rs:239-263): LTVariable::constant(domain_tag), the inputs, LTVariable::zero()
@@ -181,21 +195,42 @@ __global__ __launch_bounds__(128) void k_poseidon_gadget(PoseidonGadgetArgs<P> a
         st[i] = fx_zero<P>();
         if (i - 1 < a.arity) {
             if (a.input_vars) {
-                const uint32_t v = a.input_vars[h * a.arity + (i - 1)];
+                const uint32_t v = a.input_vars[hh * a.arity + (i - 1)];
                 if (v != ZKT_VARIABLE_ZERO) {
                     if (v < a.n_vars) st[i] = fx_unpack<P>(fe_load<P>(a.vars + v));
                     else ok = false;
                 }
             } else {
-                st[i] = fx_unpack<P>(fe_load<P>(a.inputs + h * a.arity + (i - 1)));
+                st[i] = fx_unpack<P>(fe_load<P>(a.inputs + hh * a.arity + (i - 1)));
             }
         }
     }
-    if (!ok) {
-        atomicOr(a.status, 1u);
-        return;
-    }
-    Fe<P>* out = a.vars + base;
+    const bool run = have && ok;
+    if (have && !ok) atomicOr(a.status, 1u);
+    sbase[wv][lane] = run ? base : ~(uint64_t)0;
+    uint4* mystage = stage[wv];
+    uint32_t cnt = 0;          // variables staged since the last flush (the same in every thread: the schedule is uniform)
+    uint64_t pos = 0;          // variables flushed so far
+    auto flush = [&](uint32_t k_count) {
+        __syncthreads();
+        // 16-byte chunk c of the wavefront's k_count x 64 variables: hash c / (2 k_count), then variable, then half
+        const uint32_t per = 2u * k_count;
+        for (uint32_t c = lane; c < 64u * per; c += 64u) {
+            const uint32_t hsh = c / per, part = c - hsh * per, k = part >> 1, half = part & 1u;
+            const uint64_t b = sbase[wv][hsh];
+            if (b != ~(uint64_t)0)
+                reinterpret_cast<uint4*>(a.vars + b + pos + k)[half] = mystage[(k * 64u + hsh) * 2u + half];
+        }
+        __syncthreads();
+        pos += k_count;
+        cnt = 0;
+    };
+    auto emit = [&](const Fx<P>& x) {
+        const Fe<P> v = fx_pack<P>(x);
+        mystage[(cnt * 64u + lane) * 2u] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        mystage[(cnt * 64u + lane) * 2u + 1u] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        if (++cnt == (uint32_t)K) flush(K);
+    };
     const uint32_t* rc = a.rc_a;
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
@@ -211,11 +246,11 @@ __global__ __launch_bounds__(128) void k_poseidon_gadget(PoseidonGadgetArgs<P> a
             if (i == 0 || full) {
                 const Fx<P> xs = fx_shl_sh<P>(st[i]);
                 const Fx<P> x2 = gadget_mul<P>(st[i], xs);
-                fe_store<P>(out++, fx_pack<P>(x2));
+                emit(x2);
                 const Fx<P> x4 = gadget_mul<P>(x2, fx_shl_sh<P>(x2));
-                fe_store<P>(out++, fx_pack<P>(x4));
+                emit(x4);
                 st[i] = gadget_mul<P>(x4, xs);
-                fe_store<P>(out++, fx_pack<P>(st[i]));
+                emit(st[i]);
             }
         }
         // product_mds (spec.rs:73-88): for j, for i: val = add_gate(val, mul_constant(state[i], m[i][j])): W^2 variables
@@ -226,14 +261,15 @@ __global__ __launch_bounds__(128) void k_poseidon_gadget(PoseidonGadgetArgs<P> a
             for (int i = 0; i < W; ++i) {
                 const Fx<P> t = fx_cond_sub_p<P>(fx_mul<P>(st[i], fx_load_limbs<P>(a.mds + 9 * (i * W + j))));
                 acc = fx_cond_sub_p<P>(fx_add<P>(acc, t));
-                fe_store<P>(out++, fx_pack<P>(acc));
+                emit(acc);
             }
             nx[j] = acc;
         }
 #pragma unroll
         for (int j = 0; j < W; ++j) st[j] = nx[j];
     }
-    if (a.out) fe_store<P>(a.out + h, fx_pack<P>(st[1]));   // spec.rs:315: elements[1]
+    if (cnt) flush(cnt);
+    if (a.out && run) fe_store<P>(a.out + h, fx_pack<P>(st[1]));   // spec.rs:315: elements[1]
 }
 
 
