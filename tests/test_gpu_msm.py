@@ -214,8 +214,8 @@ def test_msm_full_size_2_20(cv, ctxs):
 def test_msm_2_21_wide_pairs_and_wide_digits(ctxs):
     """BN254 at n = 2^21: the table index no longer fits a 4-byte pair (26 index bits), so the level-1 split writes
     (key, value) pairs; from this size on the digits are 19 bits wide (14 windows, 2^18 buckets), which takes the
-    1024-column level-2 tables and the generic digit loop -- a combination the prover's configs do not reach.  Canonical and
-    Montgomery scalars, against the oracle."""
+    1024-column level-2 tables (and DigitLayout<5>) -- a combination the prover's configs do not reach on this curve.
+    Canonical and Montgomery scalars, against the oracle."""
     cv = F.BN254
     ctx = ctxs[cv.name]
     n = 1 << 21

@@ -236,11 +236,12 @@ template <> struct DigitLayout<1> { static constexpr int LO = 17, REM = 0, W = 1
 template <> struct DigitLayout<2> { static constexpr int LO = 17, REM = 1, W = 15; };   // 256 bits = 18 + 14 x 17
 template <> struct DigitLayout<3> { static constexpr int LO = 18, REM = 4, W = 14; };   // 256 bits = 4 x 19 + 10 x 18 (BLS12-381, n = 2^20)
 template <> struct DigitLayout<4> { static constexpr int LO = 19, REM = 9, W = 13; };   // 256 bits = 9 x 20 + 4 x 19 (BLS12-381, n = 2^22)
-constexpr int MSM_DIGIT_LAYOUTS = 4;
+template <> struct DigitLayout<5> { static constexpr int LO = 18, REM = 3, W = 14; };   // 255 bits = 3 x 19 + 11 x 18 (BN254, c = 19)
+constexpr int MSM_DIGIT_LAYOUTS = 5;
 static int msm_digit_layout(const MsmWindows& win, int total_bits) {
-    static const int los[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::LO, DigitLayout<2>::LO, DigitLayout<3>::LO, DigitLayout<4>::LO};
-    static const int rems[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::REM, DigitLayout<2>::REM, DigitLayout<3>::REM, DigitLayout<4>::REM};
-    static const int ws[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::W, DigitLayout<2>::W, DigitLayout<3>::W, DigitLayout<4>::W};
+    static const int los[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::LO, DigitLayout<2>::LO, DigitLayout<3>::LO, DigitLayout<4>::LO, DigitLayout<5>::LO};
+    static const int rems[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::REM, DigitLayout<2>::REM, DigitLayout<3>::REM, DigitLayout<4>::REM, DigitLayout<5>::REM};
+    static const int ws[MSM_DIGIT_LAYOUTS + 1] = {0, DigitLayout<1>::W, DigitLayout<2>::W, DigitLayout<3>::W, DigitLayout<4>::W, DigitLayout<5>::W};
     for (int dig = 1; dig <= MSM_DIGIT_LAYOUTS; ++dig) {
         const int lo = los[dig], rem = rems[dig], W = ws[dig];
         if (win.W != W || W * lo + rem != total_bits) continue;
@@ -907,6 +908,7 @@ static auto msm_pick_bin_count(int dig) -> decltype(&k_msm_bin_count<C, 0>) {
         case 2: return k_msm_bin_count<C, 2>;
         case 3: return k_msm_bin_count<C, 3>;
         case 4: return k_msm_bin_count<C, 4>;
+        case 5: return k_msm_bin_count<C, 5>;
         default: return k_msm_bin_count<C, 0>;
     }
 }
@@ -917,6 +919,7 @@ static auto msm_pick_bin_scatter(int dig) -> decltype(&k_msm_bin_scatter<C, PF, 
         case 2: return k_msm_bin_scatter<C, PF, 2>;
         case 3: return k_msm_bin_scatter<C, PF, 3>;
         case 4: return k_msm_bin_scatter<C, PF, 4>;
+        case 5: return k_msm_bin_scatter<C, PF, 5>;
         default: return k_msm_bin_scatter<C, PF, 0>;
     }
 }
