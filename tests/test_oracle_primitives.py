@@ -170,3 +170,37 @@ def test_ntt_against_sympy(f):
         assert cev == [int(x) for x in ntt(shifted, prime=p)]
         assert dom.coset_ifft(cev) == coeffs
         assert dom.coset_ifft(ev) == [int(x) * pow(g, -j, p) % p for j, x in enumerate(intt(ev, prime=p))]
+
+
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
+def test_curve_arithmetic_and_msm_against_sympy(cv):
+    """A second independent implementation: sympy.ntheory.elliptic_curve.EllipticCurve (affine chord-and-tangent over Z_q)
+    on y^2 = x^3 + b with the published G1 generators.  Scalar multiples, sums, doublings, the order of the generator, a
+    small multi-scalar multiplication (oracle.curve's Pippenger and the C++ port's) and a short SRS (powers of a trapdoor)
+    must agree -- the group law and the MSM results rest on more than this repository's own code."""
+    from sympy.ntheory.elliptic_curve import EllipticCurve
+    from oracle import coracle as K
+    E = EllipticCurve(0, cv.b, modulus=cv.fq.p)
+    Gs = E(cv.gx, cv.gy)
+    G = C.generator(cv)
+    xy = lambda pt: (int(pt.x), int(pt.y))
+    r = cv.fr.p
+    scalars = [1, 2, 3, 0xFFFF, r - 1] + field_elems(r, 77, 6)
+    pts = []
+    for k in scalars:
+        want = xy(k * Gs)
+        assert C.scalar_mul(cv, k, G) == want
+        pts.append(want)
+    assert C.add(cv, pts[1], pts[2]) == xy(5 * Gs) and C.double(cv, pts[3]) == xy((2 * 0xFFFF) * Gs)
+    assert C.add(cv, pts[4], G) is None                                    # (r - 1) G + G = O: the generator has order r
+    coeffs = field_elems(r, 78, len(pts))
+    acc = None
+    for s, (k, _) in zip(coeffs, zip(scalars, pts)):
+        acc = (s * k) % r if acc is None else (acc + s * k) % r
+    want = xy(acc * Gs)
+    assert C.msm_pippenger(cv, pts, coeffs) == want
+    out, inf = K.msm_mont(cv, K.points_to_mont(cv, pts), K.fr_to_mont(cv, coeffs))
+    assert not inf and K.points_from_mont(cv, out)[0] == want
+    tau = 0xC0FFEE
+    srs = K.points_from_mont(cv, K.srs_mont(cv, tau, 6))
+    assert srs == [xy(pow(tau, i, r) * Gs) for i in range(6)]
