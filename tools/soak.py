@@ -38,7 +38,13 @@ for k, circ in enumerate(circs):
     pi_vals = B.fr_to_mont_gpu(ctx, fld, [circ["pi"][i] for i in pi_pos])
     bl = B.fr_to_mont_gpu(ctx, fld, [rnd.randrange(fld["r"]) for _ in range(z.NUM_BLINDERS)])
     for tb in tables:
-        if k % 2 == 0:
+        if k == 2:      # the composer's own layout in HBM (variables + wire indices; prove.rs:49-55 runs on the device)
+            dv = torch.from_numpy(np.concatenate(hw).view(np.int64)).to(dev)
+            di = [torch.from_numpy((np.arange(gates, dtype=np.uint32) + np.uint32(j * gates)).view(np.int32)).to(dev) for j in range(3)]
+            keep.append((dv, di))
+            preps.append(ctx.prepare_vars_dev(dv.data_ptr(), 3 * gates, di[0].data_ptr(), di[1].data_ptr(), di[2].data_ptr(), gates, tb,
+                                              pi_pos, pi_vals, bl))
+        elif k % 2 == 0:
             dw = [torch.from_numpy(x.view(np.int64)).to(dev) for x in hw]
             keep.append(dw)
             preps.append(ctx.prepare_dev(dw[0].data_ptr(), dw[1].data_ptr(), dw[2].data_ptr(), gates, tb, pi_pos, pi_vals, bl))
