@@ -53,6 +53,11 @@ class TorchComm:
             if on_device:
                 s = torch.as_tensor(_DevBuf(send, nbytes), device=self.device)
                 r = torch.as_tensor(_DevBuf(recv, nbytes * self.world), device=self.device)
+                if recv <= send < recv + nbytes * self.world:
+                    # the library sends from inside its receive buffer (RCCL's in-place form).  Whether
+                    # torch.distributed accepts aliased tensors there has never been seen on more than one GPU: give
+                    # the send data a buffer of its own (one device-to-device copy of 4n * 32 / world bytes)
+                    s = s.clone()
                 dist.all_gather_into_tensor(r, s)
                 torch.cuda.synchronize(self.device)          # contract: complete when the callback returns
                 return 0
