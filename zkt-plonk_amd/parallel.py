@@ -4,8 +4,8 @@
     bench.py reports.
 (b) ONE proof across the ranks (`TorchComm`, `LocalGroup`: the communicator behind zkt_ctx_set_comm): index-range MSMs
     whose partial sums are all-gathered as raw bytes (a collective cannot reduce curve points) and ONE all-gather of the
-    quotient evaluations (4n x 32 B in total) per proof.  The device branch of TorchComm (in-place
-    all_gather_into_tensor on the library's HBM buffer over RCCL) has run with a world of one only: the pool gives
+    quotient evaluations (4n x 32 B in total) per proof.  The device branch of TorchComm
+    (all_gather_into_tensor on the library's HBM buffer over RCCL, the send slice copied out first) has run with a world of one only: the pool gives
     one GPU per box, so the multi-GPU device transport is UNVERIFIED ON HARDWARE; bench.py fails (exit 4) if its
     bytes ever differ from the single-GPU proof's.
 `sharded_msm_combine` is the one exchange step of an MSM whose points are split by index range."""
