@@ -14,7 +14,7 @@ print(sys.argv[2], d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"],
 PY
 }
 run bn254_2_14 --log-n 14 --steps 20 --warmup 3 &&
-run bn254_2_18 --log-n 18 --steps 20 --warmup 3 &&
+run bn254_2_18 --log-n 18 --steps 40 --warmup 3 --inflight 2 &&
 run bn254_2_19 --log-n 19 --steps 20 --warmup 3 &&
 run bls12_381_2_20 --curve bls12_381 --log-n 20 --steps 5 --warmup 1 --no-cpu-baseline &&
 run bls12_381_2_22 --curve bls12_381 --log-n 22 --steps 3 --warmup 1 --no-cpu-baseline
