@@ -54,8 +54,10 @@ FIELDS = {
 }
 K1, K2 = 7, 13
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MAD_CYCLES = 4.7               # measured v_mad_u64_u32 cycles / wave-instr / SIMD at the 2-4 waves per SIMD the
-                               # accumulation holds (profiles/microbench_r03.txt; 4.4 is the 8-wave figure)
+MAD_CYCLES = 4.4               # best measured v_mad_u64_u32 issue cost, cycles / wave-instr / SIMD (8 waves resident,
+                               # profiles/microbench_r03.txt): the ceiling of frac_of_mad_issue_ceiling (r01-r03 and r05 lines)
+MAD_CYCLES_RESIDENT = 4.7      # the same at the 2-4 waves per SIMD the accumulation holds (r04's line used this one;
+                               # reported beside it as frac_of_mad_issue_ceiling_at_residency)
 CLOCK_HZ = 2.4e9
 N_SIMD = 256 * 4
 
@@ -376,7 +378,8 @@ def main():
     elapsed = time.perf_counter() - t_start
     barrier()
     prof_acc = ctx.profile_get("msm_accumulate")
-    scope_names = ("msm_accumulate", "msm_main", "msm_fold", "msm_tail", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2), "quotient",
+    prof_idle = ctx.profile_get("host_wait")
+    scope_names = ("msm_accumulate", "msm_main", "msm_lag_accumulate", "msm_lag_main", "msm_fold", "msm_tail", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2), "quotient",
                    "round1", "round2", "round3", "round4", "round5")
     prof_steps = max(2, min(args.steps, 6))
     ctx.profile_enable(1)
@@ -536,7 +539,11 @@ def main():
         "kernel": "k_msm_accumulate", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_acc_s * 1e3, 4), "launches": acc_calls,
+        "launches_are": "the dense commitments only (coefficient-form MSMs of n + 2 .. n + 3 scalars); the Lagrange-basis "
+                        "commitments of t / h1 / h2 / z2 run the same kernel over a few thousand pairs and are listed under "
+                        "`commitments`",
         "frac_of_mad_issue_ceiling": round(mads_per_add * mixed_adds / avg_acc_s / mad_ceiling, 4) if avg_acc_s > 0 else None,
+        "frac_of_mad_issue_ceiling_at_residency": round(mads_per_add * mixed_adds / avg_acc_s / (mad_ceiling * MAD_CYCLES / MAD_CYCLES_RESIDENT), 4) if avg_acc_s > 0 else None,
         "valu_busy": valu_busy, "valu_busy_source": valu_src,
         "note": "integer-ALU bound (v_mad_u64_u32 issue), not HBM bound: the contract's HBM fraction is reported, the "
                 "binding ceiling is frac_of_mad_issue_ceiling (see int_alu); traffic = measured gather traffic of W*n "
@@ -552,6 +559,24 @@ def main():
         "msm_avg_ms": round(avg_msm_s * 1e3, 4), "msm_launches": msm_calls,
         "msm_main_stream_avg_ms": round(msm_ms / max(msm_calls, 1), 4),
         "msm_tail_avg_ms": round((tail_ms + fold_ms) / max(tail_calls, 1), 4),
+        "frac_of_mad_issue_ceiling_at_residency": roofline["frac_of_mad_issue_ceiling_at_residency"],
+        "ceilings": "frac_of_mad_issue_ceiling prices a multiply-add at %.1f cycles (the best measured issue rate, the r01-r03 "
+                    "definition); _at_residency at %.1f (the rate at the kernel's 3 waves per SIMD, r04's definition)" % (MAD_CYCLES, MAD_CYCLES_RESIDENT),
+    }
+    lag_calls, lag_ms = prof["msm_lag_main"]
+    lag_acc_calls, lag_acc_ms = prof["msm_lag_accumulate"]
+    lag_info = ctx.lagrange_info()
+    per_proof = lambda calls: round(calls / float(prof_steps), 2)
+    commitments = {
+        "dense_msms_per_proof": per_proof(msm_calls), "lagrange_msms_per_proof": per_proof(lag_calls),
+        "lagrange_main_stream_avg_ms": round(lag_ms / lag_calls, 4) if lag_calls else None,
+        "lagrange_accumulate_avg_ms": round(lag_acc_ms / lag_acc_calls, 4) if lag_acc_calls else None,
+        "lagrange_table_bases": lag_info["bases"],
+        "is": "h1, h2, z2 (and t when the table changes) are piecewise constant as evaluation vectors; they are committed in "
+              "the Lagrange basis of the domain, where the MSM's scalars are the differences of neighbouring evaluations "
+              "(include/zkt_plonk.h zkt_commit_evals_dev): the same points, hence the same proof bytes, as the "
+              "reference's coefficient-form commitments (prove.rs:166-180,249-251); a circuit with dense lookups gains "
+              "nothing and loses nothing",
     }
     # NTT: HBM fraction (the BASELINE metric) and the fraction of the mad ceiling.  Products per transform: one twiddle
     # product per butterfly output that has a non-unit twiddle, (N/2) log2 N at most; L^2-term schoolbook + reduction
@@ -581,18 +606,32 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["describe"], "parallelism": "proofs sharded across %d GPU(s)" % world,
                    "chained": bool(chain), "distinct_witnesses": 2, "witness_on_device": True, "table_cached": True,
+                   "lagrange_commits": lag_info["log_n"] == log_n,
                    "proof_bytes": len(proof), "setup_s": round(setup_s, 1)},
-        "roofline": roofline, "int_alu": int_alu, "kernels": ntt,
+        "roofline": roofline, "int_alu": int_alu, "commitments": commitments, "kernels": ntt,
         "rounds_ms": {k: round(prof[k][1] / prof[k][0], 3) for k in ("round1", "round2", "round3", "round4", "round5") if prof[k][0]},
         "kernels_measured": "msm_accumulate: HIP events inside the timed region; the other scopes and rounds_ms: %d further "
                             "chained proofs with every scope on, outside the timed region (stream time, first to last "
                             "launch of the scope; round4 / round5 contain the early round1 / round2 of the next proof)" % prof_steps,
     }
+    if prof_idle[0]:
+        idle_ms = prof_idle[1] / args.steps
+        out["gpu_active"] = {
+            "main_stream_busy_ms_per_proof": round(ms_per_step - idle_ms, 3), "main_stream_idle_ms_per_proof": round(idle_ms, 3),
+            "busy_frac": round(1.0 - idle_ms / ms_per_step, 4), "host_round_trips_per_proof": round(prof_idle[0] / args.steps, 2),
+            "is": "HIP events on the proving stream inside the timed region: idle = from the moment the stream drains while the "
+                  "host waits for a round's commitments / evaluations until the next launch (zkt_profile_get \"host_wait\"); "
+                  "busy = wall clock per proof minus that.  The bucket-reduction tails run on a side stream during part of "
+                  "the idle time",
+        }
     if wl.get("witness") is not None:
         out["witness"] = wl["witness"]
         out["poseidon_witness_ms"] = wl["witness"]["device_ms"]
     if latency is not None:
         out["latency"] = latency
+        # the stricter regimes as first-class figures beside `value` (proofs/s of back-to-back single proofs)
+        out["value_unchained"] = round(1e3 / latency["unchained_single_proof_ms"], 4)
+        out["value_cold"] = round(1e3 / latency["cold_single_proof_ms"], 4)
     if inflight is not None:
         out["inflight"] = inflight
     if verify is not None:

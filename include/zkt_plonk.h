@@ -67,9 +67,12 @@ int zkt_ctx_synchronize(zkt_ctx* ctx);
  * bucket fold of one MSM), "msm_accumulate" (the accumulation kernel alone), "msm_fold" / "msm_tail" (bucket fold and
  * reduction, on the side stream), "quotient", and the prover's rounds as stream time between their first and last
  * launch: "round1", "round2" (prove.rs:116-185; issued early when announced by zkt_prove_set_next), "round3"
- * (:190-255), "round4" (:258-313), "round5" (:318-451).
- * on = 0: off; 1: every scope; 2: only "msm_accumulate" -- the level for timing the dominant kernel live inside a
- * throughput measurement (one event pair per MSM instead of ~80 records per proof). */
+ * (:190-255), "round4" (:258-313), "round5" (:318-451); "msm_lag_main" / "msm_lag_accumulate": the same two scopes for
+ * commitments taken in the Lagrange basis (their pairs are few, they would dilute the dense kernel's average);
+ * "host_wait": idle time of the context's stream across the prover's host round trips (from the moment the stream
+ * drains while the host waits for a round's commitments or evaluations to the next launch; six per proof).
+ * on = 0: off; 1: every scope; 2: only "msm_accumulate" and "host_wait" -- the level for timing the dominant kernel
+ * and the stream's idle time live inside a throughput measurement (~18 event pairs per proof instead of ~80). */
 int zkt_profile_enable(zkt_ctx* ctx, int on);
 int zkt_profile_get(zkt_ctx* ctx, const char* name, uint64_t* calls, double* total_ms);
 const char* zkt_version(void);
@@ -174,6 +177,28 @@ int zkt_msm_g1_dev(zkt_ctx* ctx, const void* d_scalars, size_t len, size_t base_
 int zkt_msm_enqueue_dev(zkt_ctx* ctx, const void* d_scalars, size_t len, size_t base_offset, int scalars_montgomery);
 /* Window size c, number of windows and loaded powers of the current SRS (0s when none). */
 int zkt_msm_info(zkt_ctx* ctx, int* window_bits, int* windows, size_t* srs_count);
+
+/* ---- Commitments of evaluation vectors (Lagrange-basis key) ------------------------------------------
+ * The reference commits to t, h1, h2 and z2 through their coefficients (prove.rs:145-180,225-251: poly_from_evals,
+ * add_blinders_to_poly, PC::commit -- one dense MSM each).  As EVALUATION vectors they are piecewise constant (table
+ * values then zeros, sorted runs, a grand product whose ratio is 1 wherever the lookup stands still), so the library
+ * commits to them in the Lagrange basis of the circuit's domain: with S_k = sum_{i<k} [L_i(tau)] G,
+ *     commit = sum_k (e_(k-1) - e_k) S_k + sum_j b_j ([tau^(n+j)] G - [tau^j] G),
+ * an MSM whose scalars vanish inside every run.  The same group element, so the same proof bytes; a dense vector costs
+ * what its coefficients would.  The second base table (prefix sums of the inverse DFT of the powers over G1, plus the
+ * blinder points; as large as the first) is built on the first proof after a key or circuit change -- about 0.3 s at
+ * n = 2^20 on BN254 -- when the key is whole (not a slice of a sharded key) and holds more than n powers; otherwise,
+ * or after zkt_ctx_set_lagrange(ctx, 0), the coefficients are committed as the reference does. */
+int zkt_ctx_set_lagrange(zkt_ctx* ctx, int on);
+/* *log_n = domain the table serves (-1: none, evaluations go through their coefficients), *bases = its points */
+int zkt_lagrange_info(zkt_ctx* ctx, int* log_n, size_t* bases);
+/* PC::commit of poly_from_evals(domain, evals) (util.rs:63-86) with k in 0..3 blinders added as add_blinders_to_poly
+ * does (prove.rs:472-483); the domain is the loaded circuit's.  d_evals: n elements in HBM; blinders: k x 4 words,
+ * host.  path 0 = through the coefficients (the reference's route), 1 = through the Lagrange-basis table (built if
+ * need be; ZKT_ERR_NOT_LOADED when the key cannot carry one).  Both give the same affine point (x || y Montgomery
+ * limbs on the host, (0,0) and *out_is_infinity = 1 for the identity).  Synchronises the stream. */
+int zkt_commit_evals_dev(zkt_ctx* ctx, const void* d_evals, const uint64_t* blinders, int k, int path, uint64_t* out_xy_mont,
+                         int* out_is_infinity);
 
 /* ---- Fiat-Shamir transcripts (host side; T: TranscriptProtocol, plonk-core/src/transcript.rs:16-45) */
 enum {

@@ -737,6 +737,30 @@ class Context:
         self.check(self._L.zkt_msm_info(self._h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(n)))
         return dict(window_bits=c.value, windows=w.value, srs_count=n.value)
 
+    # -- commitments of evaluation vectors (Lagrange-basis key, include/zkt_plonk.h) ----------------------
+    def set_lagrange(self, on: bool = True):
+        self._L.zkt_ctx_set_lagrange.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.check(self._L.zkt_ctx_set_lagrange(self._h, int(on)))
+
+    def lagrange_info(self):
+        self._L.zkt_lagrange_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t)]
+        lg, nb = ctypes.c_int(0), ctypes.c_size_t(0)
+        self.check(self._L.zkt_lagrange_info(self._h, ctypes.byref(lg), ctypes.byref(nb)))
+        return dict(log_n=lg.value, bases=nb.value)
+
+    def commit_evals_dev(self, d_evals: int, blinders=None, path: int = 1):
+        """PC::commit(poly_from_evals(evals) + blinders): path 0 through the coefficients, 1 through the Lagrange basis.
+        -> (xy Montgomery limbs, is_infinity); the domain is the loaded circuit's."""
+        self._L.zkt_commit_evals_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
+                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+        k = 0 if blinders is None else int(np.asarray(blinders).reshape(-1, 4).shape[0])
+        bl = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1, 4) if k else None
+        out = np.zeros(2 * self.fq_limbs, dtype=np.uint64)
+        inf = ctypes.c_int(0)
+        self.check(self._L.zkt_commit_evals_dev(self._h, ctypes.c_void_p(d_evals), u64p(bl) if k else None, k, int(path),
+                                                u64p(out), ctypes.byref(inf)))
+        return out, bool(inf.value)
+
     # -- prover -----------------------------------------------------------------------------------------
     def circuit_load(self, log_n: int, pk_polys):
         """pk_polys: 10 arrays (len_k, 4) in the order q_m q_l q_r q_o q_c sigma1 sigma2 sigma3 q_lookup q_table."""

@@ -114,7 +114,7 @@ ProfScope::ProfScope(zkt_ctx* ctx, const char* name, hipStream_t on_stream, uint
     if (!c->prof_on) return;
     // every event pair is a few microseconds of stream time: the light level keeps only the dominant kernel's scope, so
     // that a throughput measurement can time that kernel live without paying for ~80 other records per proof
-    if (c->prof_on == 2 && strcmp(name, "msm_accumulate") != 0) return;
+    if (c->prof_on == 2 && strcmp(name, "msm_accumulate") != 0 && strcmp(name, "host_wait") != 0) return;
     stream = on_stream ? on_stream : c->stream;
     slot = &c->prof[name];
     e0 = prof_event(c);

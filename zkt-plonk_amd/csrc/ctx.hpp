@@ -60,6 +60,7 @@ struct zkt_ctx {
     std::shared_ptr<zkt::MsmState> msm;
     uint64_t msm_epoch = 0;   // bumped by every MSM enqueue and SRS (re)load: work issued ahead of time is tied to it
     uint64_t srs_generation = 0;   // bumped by every SRS (re)load: cached commitments are tied to the key they were made under
+    bool lagrange_off = false;     // zkt_ctx_set_lagrange(ctx, 0): evaluations are committed through their coefficients
     std::shared_ptr<zkt::CircuitState> circuit;
     std::vector<void*> owned;  // every hipMalloc made on behalf of this ctx
 };

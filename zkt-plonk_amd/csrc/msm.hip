@@ -24,6 +24,7 @@
 #include "ec.hpp"
 #include "ecx.hpp"
 #include "hostec.hpp"
+#include "msm.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -31,73 +32,6 @@
 #include <cstring>
 
 namespace zkt {
-
-constexpr int MSM_CHUNK_MIN = 16;  // grouped pairs per accumulation thread: at least this many; the actual
-                                   // chunk is sized so that ONE resident wave-front of threads covers the array
-constexpr int MSM_R2_BLOCKS = 1;     // partial sums per row handed to the host
-constexpr int MSM_MAX_Y = 24;
-
-// Window layout: W windows of width c or c-1 covering exactly lambda+1 bits, so that no window
-// (in particular not the top one) is left with only a few significant bits: a 2-bit top window
-// would pour n entries into 4 buckets.
-struct MsmWindows {
-    int W;
-    uint8_t width[40];
-    uint16_t start[40];
-};
-
-constexpr int MSM_HEAVY = 32;       // buckets with more pieces than this are folded by a whole block
-constexpr int MSM_HEAVY_BLOCKS = 64;     // grid-stride over the (normally empty) list of crowded buckets
-
-struct MsmState {
-    size_t count = 0;      // bases loaded
-    // index-range sharding: this GPU holds powers [slice_off, slice_off + count) of a key of `total`
-    size_t slice_off = 0, total = 0;
-    int c = 0, W = 0;      // max window bits, windows
-    MsmWindows win{};
-    uint32_t* heavy[11] = {};   // per slot: [0] = count, [1..] = heavy bucket ids
-    uint32_t B = 0;        // buckets = 2^(c-1), ids 1..B
-    void* table = nullptr; // Affine[W][count]
-    // work buffers (sized for n = count)
-    uint32_t* vals2 = nullptr;                     // table indices grouped by bucket
-    void* pairs = nullptr;                         // uint2[m]: after the level-1 split
-    uint32_t* bin_offs = nullptr;                  // [nb1][blocks] level-1 counts, scanned per 4096-tile
-    uint32_t* bin_aux = nullptr;                   // tile totals, scanned; last = number of pairs
-    uint32_t *bin_start = nullptr, *tile_start = nullptr;   // nb1 + 1 each: level-2 work list
-    void* tile_desc = nullptr;                     // uint2[l2_items]: pair range of every level-2 tile
-    uint32_t *cnt2 = nullptr, *pos2 = nullptr;     // [level-2 tiles][256]
-    uint32_t* chunk_bucket = nullptr;              // bucket of the first pair of every accumulation chunk
-    uint32_t nb1 = 0;                              // level-1 bins
-    uint32_t lb = 8;                               // level-2 key bits: bucket = (bin << lb) | low
-    int lcols = 8;                                 // log2 columns of the level-2 tables (8, or 10 for more than 2^17 buckets)
-    bool packed = false;                           // (low key, table index, sign) fit ONE 32-bit word: 4-byte pairs
-    int dig = 0;                                   // compile-time window layout of the level-1 kernels (0: generic)
-    uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
-    uint32_t l2_items = 0;                         // upper bound of level-2 tiles
-    // per slot, because the bucket fold that reads them runs on the side stream while the next MSM is already grouping
-    uint32_t* offsets[11] = {};   // B + 2
-    void* pieces[11] = {};        // XyzzRaw[max_chunks + B + 2]
-    // The latency-bound tail of an MSM (bucket reduction) runs on a side stream so that it overlaps the
-    // next MSM's accumulation; each in-flight MSM owns one slot of tail buffers.
-    static constexpr int SLOTS = 11;
-    void* buckets[SLOTS] = {};      // Xyzz[B + 1]
-    void* rowcol[SLOTS] = {};       // Xyzz[NI + NJ]: row / column sums of the bucket matrix
-    void* host_result[SLOTS] = {};  // pinned: the (rows + 1) x R2_BLOCKS partial sums the host finishes
-    void* host_result_dev[SLOTS] = {};  // the same memory as the kernels address it
-    size_t acc_lds = 0;            // dynamic LDS of k_msm_accumulate (0; ZKT_MSM_ACC_LDS caps its residency in experiments)
-    size_t acc_threads = 196608;   // chunks an MSM is cut into: resident threads of k_msm_accumulate (occupancy query) x 2
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
-    bool pending[SLOTS] = {};
-    ~MsmState() {
-        for (int i = 0; i < SLOTS; ++i) {
-            if (host_result[i]) (void)hipHostFree(host_result[i]);
-            if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
-            if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
-        }
-        if (side) (void)hipStreamDestroy(side);
-    }
-};
 
 // ---------------------------------------------------------------------------------------------
 // SRS: synthetic generation (test / bench trapdoor), window-multiple table
@@ -412,7 +346,8 @@ ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, 
 // crowded-bucket counter of this MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
 __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uint32_t* aux, uint32_t nt, uint32_t nblk,
                                                        uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start,
-                                                       uint2* tile_desc, uint32_t* heavy_count) {
+                                                       uint2* tile_desc, uint32_t* heavy_count, uint32_t acc_threads,
+                                                       uint32_t B, uint32_t* params) {
     __shared__ uint32_t wsum[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nt; base += 1024) {
@@ -426,6 +361,13 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uin
     if (threadIdx.x == 0) {
         aux[nt] = carry;
         *heavy_count = 0;
+        // the accumulation's chunk (msm.hpp MSM_CHUNK_MIN): carry = pairs with a non-zero digit
+        uint32_t lo = 1;
+        const uint32_t twice = 2u * (carry / B);
+        while (lo < (uint32_t)MSM_CHUNK_MIN && (lo + 1) * (lo + 1) <= twice) ++lo;
+        const uint32_t even = (uint32_t)(((uint64_t)carry + acc_threads - 1) / acc_threads);
+        params[0] = even > lo ? even : lo;
+        params[1] = carry;
     }
     __syncthreads();   // aux is complete and visible to this workgroup
     const size_t total = (size_t)nb1 * nblk;
@@ -565,8 +507,9 @@ __global__ __launch_bounds__(256) void k_msm_l2_count(const typename PF::type* p
 template <int LC>
 __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint32_t* pos2, const uint32_t* bin_start,
                                                      const uint32_t* tile_start, uint32_t* offsets, uint32_t B, uint32_t lb,
-                                                     uint32_t chunk, uint32_t* chunk_bucket) {
+                                                     const uint32_t* params, uint32_t* chunk_bucket) {
     constexpr uint32_t COLS = 1u << LC, K = COLS / 256u;
+    const uint32_t chunk = params[0];
     const uint32_t b = blockIdx.x;
     const uint32_t t0 = tile_start[b], t1 = tile_start[b + 1];
     uint32_t run[K];
@@ -684,11 +627,12 @@ __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typena
 // packed words in R' Montgomery form, the pieces are the raw limbs (XyzzRaw).
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, uint32_t chunk,
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, const uint32_t* params,
                                                         const uint32_t* offsets, const uint32_t* chunk_bucket,
                                                         const Affine<typename C::Fq>* table,
                                                         XyzzRaw<typename C::Fq>* pieces) {
     using Q = typename C::Fq;
+    const uint32_t chunk = params[0];
     const uint32_t base = offsets[1], m = offsets[B + 1];   // first / one past the last pair with a non-zero bucket
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p0 = (uint64_t)base + (uint64_t)t * chunk;
@@ -735,10 +679,11 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B, uint32_t chunk,
+__global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B, const uint32_t* params,
                                                         const XyzzRaw<typename C::Fq>* pieces,
                                                         Xyzz<typename C::Fq>* buckets, uint32_t* heavy) {
     using Q = typename C::Fq;
+    const uint32_t chunk = params[0];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..B ; bucket 0 is the identity
     if (b > B) return;
     XyzzX<Q> acc = xx_identity<Q>();
@@ -794,10 +739,11 @@ ZKT_D XyzzX<Q> block_sum_256(XyzzX<Q> acc, Xyzz<Q>* wsum) {
 
 // crowded buckets (skewed digit distributions): one block folds all pieces of one bucket
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, uint32_t chunk,
+__global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, const uint32_t* params,
                                                    const XyzzRaw<typename C::Fq>* pieces,
                                                    Xyzz<typename C::Fq>* buckets, const uint32_t* heavy) {
     using Q = typename C::Fq;
+    const uint32_t chunk = params[0];
     __shared__ Xyzz<Q> wsum[4];
     const uint32_t nheavy = heavy[0];
     const uint32_t base = offsets[1];
@@ -1015,6 +961,7 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         if ((rc = dev_alloc(c, (void**)&st->offsets[i], (((size_t)st->nb1 << st->lb) + 2) * 4))) return rc;
         if ((rc = dev_alloc(c, (void**)&st->heavy[i], ((size_t)st->B + 2) * 4))) return rc;
+        if ((rc = dev_alloc(c, (void**)&st->params[i], 16))) return rc;
     }
     {
         int blocks_per_cu = 0, cus = 0;
@@ -1041,9 +988,9 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         }
         st->acc_threads *= (size_t)over;
     }
-    // chunk = max(ceil(pairs / acc_threads), MSM_CHUNK_MIN) pairs per thread, so an MSM never cuts its pairs into more
-    // than acc_threads chunks (nor more than pairs / MSM_CHUNK_MIN): that bounds the piece array of every slot
-    size_t max_chunks = std::min((m + MSM_CHUNK_MIN - 1) / MSM_CHUNK_MIN, st->acc_threads + 1);
+    // chunk >= ceil(pairs / acc_threads) pairs per thread (k_msm_scan_aux), so an MSM never cuts its pairs into more than
+    // acc_threads chunks (nor more than it has pairs): that bounds the piece array of every slot
+    size_t max_chunks = std::min(m, st->acc_threads) + 1;
     for (int i = 0; i < MsmState::SLOTS; ++i)
         if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
@@ -1066,18 +1013,26 @@ static int msm_setup(zkt_ctx* c, size_t count) {
 }
 
 template <class C>
-static int srs_finish(zkt_ctx* c) {
+static int table_finish(zkt_ctx* c, void* table, size_t count) {
     using Q = typename C::Fq;
     MsmState& st = *c->msm;
-    unsigned blocks = (unsigned)((st.count + 127) / 128);
-    hipLaunchKernelGGL(k_srs_windows<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)st.table, st.count, st.win);
+    unsigned blocks = (unsigned)((count + 127) / 128);
+    hipLaunchKernelGGL(k_srs_windows<C>, dim3(blocks), dim3(128), 0, c->stream, (Affine<Q>*)table, count, st.win);
     ZKT_HIP(c, hipGetLastError());
-    const size_t total = (size_t)st.W * st.count;
+    const size_t total = (size_t)st.W * count;
     hipLaunchKernelGGL(k_srs_to_fx<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
-                       (Affine<Q>*)st.table, total);
+                       (Affine<Q>*)table, total);
     ZKT_HIP(c, hipGetLastError());
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
     return ZKT_OK;
+}
+template <class C>
+static int srs_finish(zkt_ctx* c) {
+    return table_finish<C>(c, c->msm->table, c->msm->count);
+}
+int msm_table_finish(zkt_ctx* c, void* table, size_t count) {
+    if (c->curve == ZKT_CURVE_BN254) return table_finish<Bn254Curve>(c, table, count);
+    return table_finish<Bls381Curve>(c, table, count);
 }
 
 void msm_release(zkt_ctx* c) {
@@ -1085,11 +1040,11 @@ void msm_release(zkt_ctx* c) {
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
-    void* ptrs[] = {st.table,     st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
+    void* ptrs[] = {st.table,     st.table2, st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
                     st.tile_start, st.cnt2,   st.pos2,  st.chunk_bucket, st.tile_desc};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
-        dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]);
+        dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]); dev_free(c, st.params[i]);
         dev_free(c, st.buckets[i]); dev_free(c, st.rowcol[i]);
     }
     c->msm.reset();
@@ -1166,20 +1121,22 @@ static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t
 
 // enqueue the whole MSM; its partial sums land in st.host_result[slot] (pinned), see msm_host_finish
 template <class C>
-static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0) {
+static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0, int tbl = 0) {
     using Q = typename C::Fq;
     using R = typename C::Fr;
     MsmState& st = *c->msm;
+    // tbl = 1: the Lagrange-prefix table of lagrange.hip (count2 bases) instead of the key's powers
+    const void* table = tbl ? st.table2 : st.table;
+    const size_t tcount = tbl ? st.count2 : st.count;
     ++c->msm_epoch;   // slot buffers change hands: anything issued ahead of time that relied on them is stale
     // the slot's buffers may still be read by the previous MSM that used this slot (side stream)
     if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
     const uint32_t m = (uint32_t)((size_t)st.W * n);
     // one chunk per thread, two wave-fronts of threads (see msm_setup): equal chunks keep the lanes balanced whatever the
     // digit distribution, the second wave-front absorbs the workgroups the side stream's kernels delayed
-    uint32_t chunk = (uint32_t)((m + st.acc_threads - 1) / st.acc_threads);
-    if (chunk < (uint32_t)MSM_CHUNK_MIN) chunk = MSM_CHUNK_MIN;
+    // (the chunk itself is computed on the device from the pairs that really exist: k_msm_scan_aux -> params[slot])
     {
-    ProfScope prof_all(c, "msm_main");
+    ProfScope prof_all(c, tbl ? "msm_lag_main" : "msm_main");   // Lagrange-basis commitments are timed apart: their pairs are few
     {
         const uint32_t S = st.l1_scalars;
         const unsigned nblk = (unsigned)((n + S - 1) / S);
@@ -1191,21 +1148,22 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         }
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
         hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
-                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, st.heavy[slot]);
+                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, st.heavy[slot], (uint32_t)st.acc_threads, st.B,
+                           st.params[slot]);
         ZKT_HIP(c, hipGetLastError());
         const size_t lds_scatter = (size_t)((3 * st.nb1 + 3) & ~3u) * 4 + (size_t)MSM_L1_CAP * (st.packed ? 4 : 8);
         const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
         if (st.packed) {
             auto ks = msm_pick_bin_scatter<C, PairPacked>(st.dig);
             hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
-                               st.count, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
+                               tcount, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
             hipLaunchKernelGGL((k_msm_l2_count<PairPacked, 8>), dim3(items), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
                                st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
         } else {
             auto ks = msm_pick_bin_scatter<C, PairWide>(st.dig);
             hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
-                               st.count, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+                               tcount, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
             auto kc2 = st.lcols == 8 ? k_msm_l2_count<PairWide, 8> : k_msm_l2_count<PairWide, 10>;
             hipLaunchKernelGGL(kc2, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
@@ -1214,7 +1172,7 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         {
             auto ksc = st.lcols == 8 ? k_msm_l2_scan<8> : k_msm_l2_scan<10>;
             hipLaunchKernelGGL(ksc, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
-                               st.tile_start, st.offsets[slot], st.B, st.lb, chunk, st.chunk_bucket);
+                               st.tile_start, st.offsets[slot], st.B, st.lb, st.params[slot], st.chunk_bucket);
         }
         if (st.packed) {
             hipLaunchKernelGGL((k_msm_l2_scatter<PairPacked, 8>), dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint32_t*)st.pairs,
@@ -1227,10 +1185,11 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
         ZKT_HIP(c, hipGetLastError());
     }
     {
-        ProfScope prof_acc(c, "msm_accumulate");
-        uint32_t max_chunks = (m + chunk - 1) / chunk;
+        ProfScope prof_acc(c, tbl ? "msm_lag_accumulate" : "msm_accumulate");
+        // as many threads as the MSM can have chunks (threads past the last chunk leave at once)
+        const uint32_t max_chunks = (uint32_t)std::min((size_t)m, st.acc_threads);
         hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), st.acc_lds, c->stream, st.vals2,
-                           st.B, chunk, st.offsets[slot], st.chunk_bucket, (const Affine<Q>*)st.table, (XyzzRaw<Q>*)st.pieces[slot]);
+                           st.B, st.params[slot], st.offsets[slot], st.chunk_bucket, (const Affine<Q>*)table, (XyzzRaw<Q>*)st.pieces[slot]);
         ZKT_HIP(c, hipGetLastError());
     }
     }
@@ -1241,9 +1200,9 @@ static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_
     {
     ProfScope prof_fold(c, "msm_fold", st.side);
     hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, st.side, st.offsets[slot], st.B,
-                       chunk, (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
+                       st.params[slot], (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
     ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, st.side, st.offsets[slot], chunk,
+    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, st.side, st.offsets[slot], st.params[slot],
                        (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
     ZKT_HIP(c, hipGetLastError());
     }
@@ -1341,13 +1300,15 @@ static int msm_run_t(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_of
 }
 
 // prover-facing batch form: begin up to MsmState::SLOTS commitments, then collect them
-int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot) {
+int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot, int tbl) {
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
     if (slot < 0 || slot >= MsmState::SLOTS) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "bad MSM slot");
-    if (n == 0 || base_off > c->msm->count || n > c->msm->count - base_off)
+    if (tbl && !c->msm->table2) return set_err(c, ZKT_ERR_NOT_LOADED, "no Lagrange-basis table built");
+    const size_t cnt = tbl ? c->msm->count2 : c->msm->count;
+    if (n == 0 || base_off > cnt || n > cnt - base_off)
         return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
-    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue<Bn254Curve>(c, d_scalars, n, base_off, mont, slot);
-    return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont, slot);
+    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue<Bn254Curve>(c, d_scalars, n, base_off, mont, slot, tbl);
+    return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont, slot, tbl);
 }
 int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy) {
     if (c->curve == ZKT_CURVE_BN254) {

@@ -1,6 +1,7 @@
 // Polynomial / evaluation-vector kernels of the prover rounds (see poly.hpp for the reference
 // lines each one replaces).  All values are Fr in Montgomery form, arkworks layout.
 #include "poly.hpp"
+#include "hostinv.hpp"
 
 namespace zkt {
 
@@ -294,6 +295,41 @@ __global__ void k_z_combine(const Fe<P>* pn, const Fe<P>* sd, Fe<P> inv_total, F
     Fe<P> v = fe_mul<P>(fe_load<P>(sd + i), inv_total);
     if (i > 0) v = fe_mul<P>(v, fe_load<P>(pn + i - 1));
     fe_store<P>(out + i, v);
+}
+
+// Scalars of a commitment taken in the Lagrange basis (lagrange.hip): the polynomial with evaluations e_i (plus, when
+// k > 0, the blinders of prove.rs:472-483 at X^(L+j) and minus themselves at X^j, L = *len its trimmed length) equals
+//     sum_{i < n} D[i] S_(i+1) + sum_t D[n + t] V_t,   D[i] = (e_i - e_(i+1)) / n  (e_n := 0),  V_t = [tau^(n+t)] - [tau^t].
+// Normally L = n: the blinders are the k extra scalars and the evaluations stay as they are.  If the top coefficients
+// happen to vanish (L < n: a constant vector, an empty table) a blinder lands on X^q, q = L + j < n, and changes every
+// evaluation by b (w^(iq) - w^(ij)); for q >= n its part beyond X^n goes to the extra scalar q - n and the rest likewise.
+template <class P>
+__global__ void k_lagrange_scalars(const Fe<P>* ev, size_t n, const uint32_t* len, const Fe<P>* bl, int k, const Fe<P>* roots,
+                                   Fe<P> ninv, Fe<P>* D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n + (size_t)k) return;
+    const size_t L = k ? (size_t)*len : n;
+    if (i >= n) {
+        const size_t t = i - n;
+        Fe<P> acc = fe_zero<P>();
+        for (int j = 0; j < k; ++j)
+            if (L + j == n + t) acc = fe_add<P>(acc, fe_load<P>(bl + j));
+        fe_store<P>(D + i, acc);
+        return;
+    }
+    Fe<P> e0 = fe_load<P>(ev + i), e1 = (i + 1 < n) ? fe_load<P>(ev + i + 1) : fe_zero<P>();
+    if (L != n) {
+        for (int j = 0; j < k; ++j) {
+            const size_t q = (L + j) & (n - 1);
+            if (q == (size_t)j) continue;
+            const Fe<P> b = fe_load<P>(bl + j);
+            e0 = fe_add<P>(e0, fe_mul<P>(b, fe_sub<P>(fe_load<P>(roots + ((i * q) & (n - 1))), fe_load<P>(roots + ((i * j) & (n - 1))))));
+            if (i + 1 < n)
+                e1 = fe_add<P>(e1, fe_mul<P>(b, fe_sub<P>(fe_load<P>(roots + (((i + 1) * q) & (n - 1))),
+                                                           fe_load<P>(roots + (((i + 1) * j) & (n - 1))))));
+        }
+    }
+    fe_store<P>(D + i, fe_mul<P>(fe_sub<P>(e0, e1), ninv));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -761,6 +797,22 @@ template <class P> static int z_combine_t(zkt_ctx* c, const void* pn, const void
     return ZKT_OK;
 }
 int z_combine(zkt_ctx* c, const void* pn, const void* sd, const uint32_t inv_total[8], void* out, size_t n) { ZKT_DISPATCH(c, z_combine_t, pn, sd, inv_total, out, n); }
+
+template <class P> static int lagrange_scalars_t(zkt_ctx* c, const void* ev, size_t n, const uint32_t* d_len, const void* d_bl, int k,
+                                                 const void* roots, void* out) {
+    Fe<P> nn = fe_zero<P>();
+    nn.v[0] = (uint32_t)(n & 0xffffffffu);
+    nn.v[1] = (uint32_t)((uint64_t)n >> 32);
+    const Fe<P> ninv = fe_inv_host<P>(fe_to_mont<P>(nn));
+    hipLaunchKernelGGL(k_lagrange_scalars<P>, dim3(nblocks(n + (size_t)k)), dim3(256), 0, c->stream, (const Fe<P>*)ev, n, d_len,
+                       (const Fe<P>*)d_bl, k, (const Fe<P>*)roots, ninv, (Fe<P>*)out);
+    ZKT_HIP(c, hipGetLastError());
+    return ZKT_OK;
+}
+int lagrange_scalars(zkt_ctx* c, const void* ev, size_t n, const uint32_t* d_len, const void* d_blinders, int k, const void* d_roots,
+                     void* out) {
+    ZKT_DISPATCH(c, lagrange_scalars_t, ev, n, d_len, d_blinders, k, d_roots, out);
+}
 
 template <class P> static FxArg hat_arg(const Fe<P>& s) {   // A form -> canonical H-form limbs
     const Fx<P> h = fx_cond_sub_p<P>(fx_from_ark<P>(s));

@@ -64,6 +64,10 @@ int poly_gather_pad(zkt_ctx* c, const void* d_values, size_t n_vars, const uint3
                     uint32_t* d_status);
 int poly_add_blinders(zkt_ctx* c, void* p, const uint32_t* d_len, const void* d_blinders, int k, size_t cap);  // prove.rs:472-483
 int poly_lincomb(zkt_ctx* c, const LinCombArgs& a, void* out, size_t n);
+// scalars (n + k of them) of a commitment taken against the Lagrange-prefix table (lagrange.hip) for the polynomial with
+// evaluations ev[0..n) and, when k > 0, the k blinders of prove.rs:472-483 appended at its trimmed length *d_len
+int lagrange_scalars(zkt_ctx* c, const void* ev, size_t n, const uint32_t* d_len, const void* d_blinders, int k, const void* d_roots,
+                     void* out);
 // d_powers: scratch of EVAL_MAX * (257 + ceil(maxlen / 2048)) elements (powers of each evaluation point)
 int poly_eval_many(zkt_ctx* c, const EvalArgs& a, void* d_partials, void* d_results, void* d_powers);         // linearization_poly.rs:55-75
 // grand products (permutation/mod.rs:181-254, lookup/mod.rs:94-151)

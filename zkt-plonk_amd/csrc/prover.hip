@@ -19,9 +19,13 @@
 
 namespace zkt {
 
-// msm.hip
+// msm.hip (tbl = 1: the Lagrange-prefix table of lagrange.hip)
 int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf);
-int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot);
+int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot, int tbl = 0);
+// lagrange.hip
+int lagrange_ensure(zkt_ctx* c, int log_n);
+bool lagrange_ready(const zkt_ctx* c, int log_n);
+size_t lagrange_bases(const zkt_ctx* c);
 int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy);
 int msm_end_sharded(zkt_ctx* c, const int* slots, const bool* have, int k, uint64_t* out_xy);
 void msm_slice(zkt_ctx* c, size_t* off, size_t* count, size_t* total);
@@ -56,6 +60,7 @@ struct CircuitState {
     void* poly[13] = {};    // a b c t h1 h2 z1 z2 pi q_lo q_mid q_hi work   (n + 8 each)
     void* wcos[W_COUNT] = {};
     void* qev = nullptr;    // 4n
+    void* lag_scalars = nullptr;   // n + 8: scalars of a commitment taken in the Lagrange basis (read by the MSM's level-1 kernels only)
     void* small = nullptr;  // blinders (19), eval partials, eval results
     uint32_t* status = nullptr;  // [0] error bits, [1] len scratch ... [4..7] quotient lens, [8..] poly lens
     uint32_t* lk_u32 = nullptr;  // lookup: perm, base counts, starts of the even half, of the odd half, hit counts
@@ -188,6 +193,15 @@ struct Prover {
     }
     static void put(uint32_t dst[8], const F& v) { memcpy(dst, v.v, 32); }
 
+    // Idle time of the main stream across a host round trip (zkt_profile_get "host_wait"): the first event is recorded
+    // behind everything enqueued when the host starts to wait (it fires when the stream drains), the second right
+    // before the next launch.  bench.py's gpu_active is the wall clock minus these.
+    std::optional<ProfScope> idle;
+    void wait_begin() {
+        if (c->prof_on && !idle) idle.emplace(c, "host_wait");
+    }
+    void wait_end() { idle.reset(); }
+
     // commitments of one round are enqueued back to back (the bucket-reduction tail of one overlaps the
     // accumulation of the next) and collected together
     // With the committer key sharded by index range, a commitment is this rank's partial sum over
@@ -203,9 +217,21 @@ struct Prover {
         const size_t l = std::min(len, off + cnt) - off;
         return msm_begin(c, (const char*)d_poly + off * 32, l, 0, 1, slot);
     }
+    // Commitment of the polynomial with evaluations `ev` plus k blinders (prove.rs:166-180,249-251), whose blinded
+    // coefficients are in d_poly.  With the Lagrange-basis table (lagrange.hip) the scalars are the differences of
+    // neighbouring evaluations: for t, h1, h2 and z2 all but a few thousand of them are zero and the MSM costs next to
+    // nothing; without it (sharded key, key shorter than n + 1) the coefficients are committed as the reference does.
+    int commit_evals_begin(const void* ev, const void* d_poly, int blinder_off, int k, int len_slot, int slot) {
+        if (!lagrange_ready(c, S.log_n) || c->lagrange_off) return commit_begin(d_poly, S.n + (size_t)k, slot);
+        int rc = lagrange_scalars(c, ev, S.n, S.status + 8 + len_slot, (const char*)S.small + (size_t)blinder_off * 32, k, S.roots,
+                                  S.lag_scalars);
+        if (rc) return rc;
+        return msm_begin(c, S.lag_scalars, S.n + (size_t)k, 0, 1, slot, 1);
+    }
     // The commitments of one prover round, collected together; skip[j]: nothing was started for entry j (out[j] is left
     // alone).  Sharded: ONE all-gather of the round's partial sums (msm.hip msm_collect_sharded).
     int commit_collect(const int* slots, const bool* skip, int k, Affine<Q>* out) {
+        wait_begin();
         if (!c->sharded()) {
             for (int j = 0; j < k; ++j) {
                 if (skip && skip[j]) continue;
@@ -270,6 +296,7 @@ struct Prover {
     int check_status() {
         uint32_t st = 0;
         ZKT_HIP(c, hipMemcpyAsync(&st, S.status, 4, hipMemcpyDeviceToHost, c->stream));
+        wait_begin();
         ZKT_HIP(c, hipStreamSynchronize(c->stream));
         if (st & 16u) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "wire index outside the variable map");
         if (st & 4u) return set_err(c, ZKT_ERR_NOT_IN_TABLE, "ElementNotIndexedInTable: a looked-up value is not in the table");
@@ -491,7 +518,7 @@ struct Prover {
         ZKT_HIP(c, hipMemsetAsync(S.ev[3], 0, n * 32, c->stream));
         if (in.table_len) ZKT_HIP(c, hipMemcpyAsync(S.ev[3], in.table, in.table_len * 32, hipMemcpyHostToDevice, c->stream));
         if ((rc = evals_to_blinded_poly(S.ev[3], S.poly[3], 0, 0, 3))) return rc;      // t: no blinders
-        if ((rc = commit_begin(S.poly[3], n, 3))) return rc;
+        if ((rc = commit_evals_begin(S.ev[3], S.poly[3], 0, 0, 3, 3))) return rc;
         if (with_coset && (rc = to_coset(W_T))) return rc;
         return ZKT_OK;
     }
@@ -510,8 +537,8 @@ struct Prover {
             const PolyJob jobs[2] = {{S.ev[5], S.poly[4], 6, 3, 4}, {S.ev[6], S.poly[5], 9, 2, 5}};   // h1: 3 blinders, h2: 2
             if ((rc = evals_to_blinded_polys(jobs, 2))) return rc;
         }
-        if ((rc = commit_begin(S.poly[4], n + 3, 4))) return rc;
-        if ((rc = commit_begin(S.poly[5], n + 2, 5))) return rc;
+        if ((rc = commit_evals_begin(S.ev[5], S.poly[4], 6, 3, 4, 4))) return rc;
+        if ((rc = commit_evals_begin(S.ev[6], S.poly[5], 9, 2, 5, 5))) return rc;
         if (!S.t_coset_valid && !table_done) return to_coset_many({W_T, W_H1, W_H2});
         return to_coset_many({W_H1, W_H2});   // unchanged table: its coset is still resident
     }
@@ -591,6 +618,7 @@ struct Prover {
         void* sd2 = (char*)S.wcos[W_Z1] + n * 32;
         mark("challenges round 3");
         std::optional<ProfScope> prof_round;   // stream time of a round, first launch to last (zkt_profile_get "round3" ...)
+        wait_end();
         prof_round.emplace(c, "round3");
         if ((rc = z1_terms(c, za))) return rc;
         if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;   // PN
@@ -609,13 +637,14 @@ struct Prover {
             const F d1 = pin[0], d2 = pin[1];
             const F inv12 = fe_inv_host<R>(fe_mul<R>(d1, d2));
             const F inv1 = fe_mul<R>(inv12, d2), inv2 = fe_mul<R>(inv12, d1);
+            wait_end();
             if ((rc = z_combine(c, S.sc[2], S.sc[3], inv1.v, S.ev[7], n))) return rc;
             if ((rc = z_combine(c, pn2, sd2, inv2.v, S.sc[0], n))) return rc;              // num / den are free again
             const PolyJob jobs[2] = {{S.ev[7], S.poly[6], 11, 3, 6}, {S.sc[0], S.poly[7], 14, 3, 7}};   // z1, z2: 3 blinders each
             if ((rc = evals_to_blinded_polys(jobs, 2))) return rc;
         }
         if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
-        if ((rc = commit_begin(S.poly[7], n + 3, 1))) return rc;
+        if ((rc = commit_evals_begin(S.sc[0], S.poly[7], 14, 3, 7, 1))) return rc;
         if ((rc = to_coset_many({W_Z1, W_Z2}))) return rc;
         // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well.  With a handful of
         // public inputs it is never built: the quotient kernel evaluates it from rotations of l1 (poly.hpp).
@@ -650,6 +679,7 @@ struct Prover {
 
         // ---- round 4 (prove.rs:258-313) ----
         const F alpha = tr_challenge("alpha");
+        wait_end();
         prof_round.emplace(c, "round4");
         {
             S.t_coset_valid = S.t_cached;
@@ -708,6 +738,7 @@ struct Prover {
 
         // ---- round 5 (prove.rs:318-451, linearization_poly.rs:19-121) ----
         const F xi = tr_challenge("xi");
+        wait_end();
         prof_round.emplace(c, "round5");
         F w;
         {
@@ -803,6 +834,7 @@ struct Prover {
         // aw opening (prove.rs:381-420): sum_k eta^k p_k over (r, a, b, c, sigma1, sigma2, q_lookup, t, h2)
         // = eta^0 * r + ... : fold r's 13 terms and the 8 others into two passes
         void* work = S.poly[12];
+        wait_end();
         if ((rc = poly_lincomb(c, lr, work, cap))) return rc;
         if (fe_is_zero<R>(xi) || fe_is_zero<R>(shifted)) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "evaluation challenge is zero");
         Affine<Q> aw, saw;
@@ -857,6 +889,7 @@ struct Prover {
                 saw = w2[1];
             }
         }
+        wait_end();
         prof_round.reset();
 
         // ---- Proof (proof.rs:106-155), CanonicalSerialize ----
@@ -897,7 +930,7 @@ void circuit_release(zkt_ctx* c) {
     fr(S.fold); fr(S.qgather);
     for (void* p : S.poly_alt) fr(p);
     fr(S.status_alt);
-    fr(S.qev); fr(S.small); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
+    fr(S.qev); fr(S.small); fr(S.lag_scalars); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
     if (S.pinned) (void)hipHostFree(S.pinned);
     if (S.pinned_pi) (void)hipHostFree(S.pinned_pi);
     if (S.copy_stream) {
@@ -966,6 +999,7 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
         if ((rc = alloc(&S.wcos[k], k == W_Z1 ? std::max(m, 2 * n) : m))) return rc;
     const size_t eval_blocks = (n + 8 + 2047) / 2048 + 1;
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
+    if ((rc = alloc(&S.lag_scalars, n + 16))) return rc;   // n + 8 scalars, then the blinders of zkt_commit_evals_dev
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status_alt, 64 * 4))) return rc;
     for (auto& p : S.poly_alt) if ((rc = alloc(&p, n + 8))) return rc;
@@ -1193,6 +1227,9 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
     if (int rc0 = check_sharded_key(c)) return rc0;
     (void)hipSetDevice(c->device);
+    // the Lagrange-basis table of this domain (lagrange.hip): built on the first proof after a key or circuit change
+    if (!c->lagrange_off)
+        if (int rc1 = lagrange_ensure(c, c->circuit->log_n)) return rc1;
     std::vector<uint8_t> proof;
     int rc;
     if (c->curve == ZKT_CURVE_BN254) {
@@ -1220,6 +1257,64 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
     if (len) *len = proof.size();
     if (proof.size() > cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "proof buffer too small");
     memcpy(out, proof.data(), proof.size());
+    return ZKT_OK;
+}
+
+// ---- commitments of evaluation vectors (lagrange.hip) --------------------------------------------------
+int zkt_ctx_set_lagrange(zkt_ctx* c, int on) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    c->lagrange_off = !on;
+    ++c->msm_epoch;   // early work of an announced proof was issued under the other setting
+    return ZKT_OK;
+}
+
+int zkt_lagrange_info(zkt_ctx* c, int* log_n, size_t* bases) {
+    if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    const bool ready = c->circuit && lagrange_ready(c, c->circuit->log_n) && !c->lagrange_off;
+    if (log_n) *log_n = ready ? c->circuit->log_n : -1;
+    if (bases) *bases = ready ? lagrange_bases(c) : 0;
+    return ZKT_OK;
+}
+
+int zkt_commit_evals_dev(zkt_ctx* c, const void* d_evals, const uint64_t* blinders, int k, int path, uint64_t* out_xy,
+                         int* out_is_infinity) {
+    if (!c || !d_evals || !out_xy || (k > 0 && !blinders)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (k < 0 || k > 3) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "0 .. 3 blinders");
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (the domain comes from it)");
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    if (c->sharded()) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "not available on a sharded key");
+    (void)hipSetDevice(c->device);
+    CircuitState& S = *c->circuit;
+    const size_t n = S.n;
+    int rc;
+    if (path == 1) {
+        if ((rc = lagrange_ensure(c, S.log_n))) return rc;
+        if (!lagrange_ready(c, S.log_n)) return set_err(c, ZKT_ERR_NOT_LOADED, "the key is too short for the Lagrange-basis table");
+    } else if (path != 0) {
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "path: 0 coefficients, 1 Lagrange basis");
+    }
+    c->circuit->prefetch_stage = 0;   // the work buffer below belongs to round 5 of an announced proof as well
+    uint32_t* d_len = S.status + 8 + 12;
+    void* d_bl = (char*)S.lag_scalars + (n + 8) * 32;
+    void* poly = S.poly[12];
+    ZKT_HIP(c, hipMemsetAsync(d_len, 0, 4, c->stream));
+    if (k) ZKT_HIP(c, hipMemcpyAsync(d_bl, blinders, (size_t)k * 32, hipMemcpyHostToDevice, c->stream));
+    // poly_from_evals + add_blinders_to_poly (util.rs:63-86, prove.rs:472-483)
+    if ((rc = ntt_run(c, S.log_n, 1, 0, d_evals, n, poly))) return rc;
+    if ((rc = poly_trim_len(c, poly, n, d_len, (char*)poly + n * 32, 8))) return rc;
+    if (k && (rc = poly_add_blinders(c, poly, d_len, d_bl, k, n + 8))) return rc;
+    if (path == 0) return msm_g1_dev(c, poly, n + (size_t)k, 0, 1, out_xy, out_is_infinity);
+    if ((rc = lagrange_scalars(c, d_evals, n, d_len, d_bl, k, S.roots, S.lag_scalars))) return rc;
+    if ((rc = msm_begin(c, S.lag_scalars, n + (size_t)k, 0, 1, 0, 1))) return rc;
+    uint64_t xy[12] = {};
+    if ((rc = msm_end(c, 0, xy))) return rc;
+    const size_t words = c->curve == ZKT_CURVE_BN254 ? 8 : 12;
+    memcpy(out_xy, xy, words * 8);
+    if (out_is_infinity) {
+        bool any = false;
+        for (size_t i = 0; i < words; ++i) any = any || xy[i] != 0;
+        *out_is_infinity = any ? 0 : 1;
+    }
     return ZKT_OK;
 }
 
