@@ -449,7 +449,9 @@ int zkt_debug_params(zkt_ctx* ctx, int which, uint32_t* out, size_t out_words);
  * packed Montgomery words (8 or 12 x u32).  op 0: product; 1: 32-bit-limb reference product;
  * 2: arkworks form -> 29-bit limbs -> arkworks form; 3: 3*(a^2 - b^2) through the lazy add/sub/mul path;
  * 4: a^-1 (host binary GCD); 5: a^-1 (the kernels' Fermat ladder); 6: a^2 + b^2 through the double product and
- * the squaring kernel; 7: (a - b) * b through the carry-free difference. */
+ * the squaring kernel; 7: (a - b) * b through the carry-free difference; 8 (nine-limb fields only): 2 (a - b) * y with
+ * y the plain value of b, through the NTT butterfly's limb-wise sums, wide carry-free difference and the product by a
+ * constant with a precomputed quotient (fx_mul_shoup); 9: 4 (a + b) through limb-wise sums and the lazy reduction. */
 int zkt_host_field_op(int curve_id, int which, int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
 /* Sum of `count` affine G1 points on the HOST (x, y arkworks Montgomery limbs each; (0, 0) = identity): the combine
  * step of an MSM whose points are sharded across GPUs by index range (the partial sums are

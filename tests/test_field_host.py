@@ -41,6 +41,11 @@ def test_host_field_ops_match_big_integers(curve, which, f):
         assert _op(L, curve, which, 6, a, b, nw) == (x * x + y * y) * R % p
         # op 7: (a - b) * b with the carry-free difference feeding the product
         assert _op(L, curve, which, 7, a, b, nw) == (x - y) * y * R % p
+        # op 8: the NTT butterfly: 2 (a - b) * y through limb-wise sums, the wide carry-free difference and the product by
+        # a constant with a precomputed quotient (no Montgomery factor: the result keeps a's form)
+        assert _op(L, curve, which, 8, a, b, nw) == 2 * (a - b) * y % p
+        # op 9: 4 (a + b) through two levels of limb-wise sums and two lazy reductions
+        assert _op(L, curve, which, 9, a, b, nw) == 4 * (a + b) % p
 
 
 @pytest.mark.parametrize("curve,which,f", FIELDS, ids=lambda x: getattr(x, "name", str(x)))

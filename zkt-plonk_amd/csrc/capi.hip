@@ -388,6 +388,25 @@ static void host_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t
         const Fx<P> two = fx_mul2_inl<P>(xa, xa, ya, ya);                        // a^2 + b^2
         const Fx<P> sq = fx_add<P>(fx_sqr_inl<P>(xa), fx_sqr_inl<P>(ya));       // the same, two reductions
         r = fx_to_ark<P>(fx_sub<P, 4>(fx_add<P>(two, two), sq));               // 2 (a^2+b^2) - (a^2+b^2)
+    } else if (op == 8) {
+        // the NTT butterfly's arithmetic: lazy sums, the wide carry-free difference, the product by a constant with a
+        // precomputed quotient.  2 (a - b) * y, y the plain value of b
+        const Fx<P> w = fx_unpack<P>(fe_from_mont<P>(y));
+        const Fx<P> wq = fx_mul_low<P>(fx_cond_sub_p<P>(fx_from_ark<P>(y)), fx_neg_p_inverse<P>());
+        const Fx<P> u = fx_unpack<P>(x), v = fx_unpack<P>(y);
+        const Fx<P> d = fx_sub_lazy_wide<P, 8, 30>(fx_add_lazy<P>(u, u), fx_add_lazy<P>(v, v));
+        r = fx_pack<P>(fx_cond_sub_p<P>(fx_cond_sub_p<P>(fx_mul_shoup<P>(d, w, wq))));
+    } else if (op == 9) {
+        // 4 (a + b) through two levels of limb-wise sums and the lazy reduction (fields whose top limb is wide enough for
+        // its quotient estimate: all but the 381-bit one)
+        if constexpr (FxP<P>::mod(FxP<P>::L - 1) >= (1u << 16)) {
+            const Fx<P> u = fx_unpack<P>(x), v = fx_unpack<P>(y);
+            const Fx<P> s = fx_add_lazy<P>(u, v);                       // < 2p, limbs < 2^30
+            const Fx<P> t = fx_reduce_lazy<P>(fx_add_lazy<P>(s, s));    // 2 (a + b), limbs < 2^31 -> < 3p, normalised
+            r = fx_pack<P>(fx_cond_sub_p<P>(fx_cond_sub_p<P>(fx_reduce_lazy<P>(fx_add_lazy<P>(t, t)))));
+        } else {
+            r = fe_dbl<P>(fe_dbl<P>(fe_add<P>(x, y)));
+        }
     } else if (op == 7) {
         const Fx<P> xa = fx_from_ark<P>(x), ya = fx_cond_sub_p<P>(fx_from_ark<P>(y));
         r = fx_to_ark<P>(fx_mul<P>(ya, fx_sub_lazy<P, 3>(xa, ya)));             // (a - b) b

@@ -120,6 +120,18 @@ struct FxP {
         }
         return out;
     }
+    // limb i of 2^(29 L) - p (normalised): adding q * this instead of subtracting q * p keeps a product chain additive
+    ZKT_HD static constexpr uint32_t nmod(int i) {
+        uint32_t out = 0;
+        uint32_t borrow = 0;
+        for (int j = 0; j <= i; ++j) {
+            // (2^29 [only conceptually, at the top] - mod(j) - borrow) mod 2^29, limb by limb from the bottom
+            const uint32_t m = mod(j) + borrow;
+            out = (0u - m) & MASK;
+            borrow = m != 0 ? 1u : 0u;
+        }
+        return out;
+    }
     // window used to estimate value / p: bits [OFS, OFS + 32) ; p >> OFS has 24 significant bits
     static constexpr int OFS = P::BITS - 24;
     ZKT_HD static constexpr uint32_t pwin() {
@@ -278,6 +290,31 @@ ZKT_HD Fx<P> fx_sub_lazy(const Fx<P>& a, const Fx<P>& b) {
     return r;
 }
 
+// a + b limb by limb, no carry pass: for sums that go through at most two such steps before a product or fx_reduce_lazy
+// brings the limbs back below 2^29 (limbs stay below 2^31)
+template <class P>
+ZKT_HD Fx<P> fx_add_lazy(const Fx<P>& a, const Fx<P>& b) {
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < FxP<P>::L; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// fx_sub_lazy for a subtrahend whose limbs may reach 2^BB (a lazy sum: BB = 30): K p is re-expressed with 2^BB borrowed
+// into every limb.  Needs b <= (K - 1) p and b's limbs <= 2^BB; result limbs < a's + 2^BB + 2^29.
+template <class P, int K, int BB>
+ZKT_HD Fx<P> fx_sub_lazy_wide(const Fx<P>& a, const Fx<P>& b) {
+    constexpr int L = FxP<P>::L;
+    static_assert(BB >= 29 && BB <= 30, "borrow of one or two limb widths");
+    constexpr uint32_t up = 1u << (BB - 29);   // what the limb above gives up
+    Fx<P> r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const uint32_t fat = FxP<P>::kmod(K, i) + (i < L - 1 ? (1u << BB) : 0u) - (i > 0 ? up : 0u);
+        r.l[i] = a.l[i] + (fat - b.l[i]);
+    }
+    return r;
+}
+
 // a + K p - b - 2c in one carry pass (b + 2c <= K p); result normalised, value < a + K p
 template <class P, int K>
 ZKT_HD Fx<P> fx_sub2(const Fx<P>& a, const Fx<P>& b, const Fx<P>& c2) {
@@ -328,6 +365,48 @@ __device__ __forceinline__ void fx_mad_rows(uint64_t& acc, const uint32_t* x, co
     } else if constexpr (N > 0) {
         if constexpr (K) MadRow<N>::vk(acc, x, y);
         else MadRow<N>::vv(acc, x, y);
+    }
+}
+
+// n multiply-adds of a column whose length is known only after the caller's loops are unrolled (n <= L <= 14)
+template <class P>
+__device__ __forceinline__ void fx_mad_rows_dyn(uint64_t& acc, const uint32_t* x, const uint32_t* y, int n) {
+    switch (n) {
+        case 0: break;
+        case 1: MadRow<1>::vv(acc, x, y); break;
+        case 2: MadRow<2>::vv(acc, x, y); break;
+        case 3: MadRow<3>::vv(acc, x, y); break;
+        case 4: MadRow<4>::vv(acc, x, y); break;
+        case 5: MadRow<5>::vv(acc, x, y); break;
+        case 6: MadRow<6>::vv(acc, x, y); break;
+        case 7: MadRow<7>::vv(acc, x, y); break;
+        case 8: MadRow<8>::vv(acc, x, y); break;
+        case 9: MadRow<9>::vv(acc, x, y); break;
+        case 10: MadRow<10>::vv(acc, x, y); break;
+        case 11: MadRow<11>::vv(acc, x, y); break;
+        case 12: MadRow<12>::vv(acc, x, y); break;
+        case 13: MadRow<13>::vv(acc, x, y); break;
+        default: MadRow<14>::vv(acc, x, y); break;
+    }
+}
+template <class P>
+__device__ __forceinline__ void fx_mad_rows_k(uint64_t& acc, const uint32_t* x, const uint32_t* y, int n) {   // y: constants
+    switch (n) {
+        case 0: break;
+        case 1: MadRow<1>::vk(acc, x, y); break;
+        case 2: MadRow<2>::vk(acc, x, y); break;
+        case 3: MadRow<3>::vk(acc, x, y); break;
+        case 4: MadRow<4>::vk(acc, x, y); break;
+        case 5: MadRow<5>::vk(acc, x, y); break;
+        case 6: MadRow<6>::vk(acc, x, y); break;
+        case 7: MadRow<7>::vk(acc, x, y); break;
+        case 8: MadRow<8>::vk(acc, x, y); break;
+        case 9: MadRow<9>::vk(acc, x, y); break;
+        case 10: MadRow<10>::vk(acc, x, y); break;
+        case 11: MadRow<11>::vk(acc, x, y); break;
+        case 12: MadRow<12>::vk(acc, x, y); break;
+        case 13: MadRow<13>::vk(acc, x, y); break;
+        default: MadRow<14>::vk(acc, x, y); break;
     }
 }
 
@@ -597,6 +676,182 @@ ZKT_HD bool fx_is_zero_canon(const Fx<P>& a) {  // a canonical
 #pragma unroll
     for (int i = 0; i < FxP<P>::L; ++i) o |= a.l[i];
     return o == 0;
+}
+
+// ---- product by a constant with a precomputed quotient (Shoup / Barrett with a per-constant reciprocal) -----------
+// For a fixed w < p let wq = floor(w * 2^(29 L) / p) (L limbs).  Then for any x < 2^(29 L)
+//     q = floor(x * wq / 2^(29 L))  is  floor(x w / p)  or one less,   and   x w - q p  is in [0, 2p).
+// q needs only the high half of x * wq: columns 7 .. 2L-2 here (dropping the seven lowest columns changes q by at most
+// one more), 53 multiply-adds for L = 9; r = x w - q p needs only the low L limbs of x w + q (2^(29 L) - p): 90.  143
+// multiply-adds and no m-chain (v_mul_lo + mask per limb) against the Montgomery product's 171: the NTT's butterfly
+// twiddles (tables in LDS, both words per entry) use it; one-off products and memory-resident tables stay Montgomery.
+// Input: limbs <= 2^31.3 (a lazy sum or difference), value < 2^(29 L); w, wq normalised.  Output normalised, < 3p.
+// No Montgomery factor is involved: x w mod p in whatever form x is in, w a plain canonical integer.
+template <class P>
+ZKT_HD Fx<P> fx_mul_shoup(const Fx<P>& x, const Fx<P>& w, const Fx<P>& wq) {
+    constexpr int L = FxP<P>::L;
+    constexpr int K0 = L - 2;          // first column of x * wq that is kept
+    uint32_t q[L];
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint64_t acc = 0;
+        bool first = true;
+#pragma unroll
+        for (int k = K0; k <= 2 * L - 2; ++k) {
+            const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+            uint32_t xs[L], ys[L];
+            int n = 0;
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) { xs[n] = x.l[i]; ys[n] = wq.l[k - i]; ++n; }
+            if (first) {
+                acc = fx_mad0(xs[0], ys[0]);
+                fx_mad_rows_dyn<P>(acc, xs + 1, ys + 1, n - 1);
+                first = false;
+            } else {
+                fx_mad_rows_dyn<P>(acc, xs, ys, n);
+            }
+            if (k >= L) q[k - L] = (uint32_t)acc & FxP<P>::MASK;
+            acc >>= 29;
+        }
+        q[L - 1] = (uint32_t)acc;
+    }
+    Fx<P> r;
+    {
+        uint64_t acc = fx_mad0(x.l[0], w.l[0]);
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            uint32_t xs[L], ys[L], qs[L], ks[L];
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i <= k; ++i) { xs[n] = x.l[i]; ys[n] = w.l[k - i]; qs[n] = q[i]; ks[n] = FxP<P>::nmod(k - i); ++n; }
+            if (k == 0) {
+                fx_mad_rows_k<P>(acc, qs, ks, 1);
+            } else {
+                fx_mad_rows_dyn<P>(acc, xs, ys, n);
+                fx_mad_rows_k<P>(acc, qs, ks, n);
+            }
+            r.l[k] = (uint32_t)acc & FxP<P>::MASK;
+            acc >>= 29;
+        }
+    }
+    return r;
+#else
+    {
+        uint64_t acc = 0;
+        for (int k = K0; k <= 2 * L - 2; ++k) {
+            for (int i = 0; i < L; ++i) {
+                const int j = k - i;
+                if (j >= 0 && j < L) acc += (uint64_t)x.l[i] * wq.l[j];
+            }
+            if (k >= L) q[k - L] = (uint32_t)acc & FxP<P>::MASK;
+            acc >>= 29;
+        }
+        q[L - 1] = (uint32_t)acc;
+    }
+    Fx<P> r;
+    uint64_t acc = 0;
+    for (int k = 0; k < L; ++k) {
+        for (int i = 0; i <= k; ++i) {
+            acc += (uint64_t)x.l[i] * w.l[k - i];
+            acc += (uint64_t)q[i] * FxP<P>::nmod(k - i);
+        }
+        r.l[k] = (uint32_t)acc & FxP<P>::MASK;
+        acc >>= 29;
+    }
+    return r;
+#endif
+}
+
+// low L limbs of a * b (normalised operands): wq = low(w^ * (-p^-1 mod 2^(29 L))) for w^ = w 2^(29 L) mod p (table setup)
+template <class P>
+ZKT_HD Fx<P> fx_mul_low(const Fx<P>& a, const Fx<P>& b) {
+    constexpr int L = FxP<P>::L;
+    Fx<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+        r.l[k] = (uint32_t)acc & FxP<P>::MASK;
+        acc >>= 29;
+    }
+    return r;
+}
+
+// value < 2^6 p with limbs up to 2^31 (lazy sums) -> normalised, < 3p, same residue: the quotient estimate comes from
+// the two top limbs (a carry pending below them can only make it smaller), the subtraction of q p is the carry pass
+template <class P>
+ZKT_HD Fx<P> fx_reduce_lazy(const Fx<P>& a) {
+    constexpr int L = FxP<P>::L;
+    // value >= top * 2^(29 (L-1)) with top = l[L-1] + (l[L-2] >> 29); p < (ptop + 1) * 2^(29 (L-1))
+    constexpr uint32_t ptop = FxP<P>::mod(L - 1);
+    static_assert(ptop >= (1u << 16), "the top limb of p must carry the quotient estimate");
+    constexpr uint32_t rec = (uint32_t)(((uint64_t)1 << 40) / ((uint64_t)ptop + 1));   // floor(2^40 / (ptop + 1))
+    const uint32_t top = a.l[L - 1] + (a.l[L - 2] >> 29);        // < 2^6 * 2^(BITS - 29 (L-1)) + 4: well below 2^32
+    const uint32_t q = (uint32_t)(((uint64_t)top * rec) >> 40);  // <= top / (ptop + 1) <= value / p
+    Fx<P> r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        int64_t v = (int64_t)a.l[i] - (int64_t)((uint64_t)q * FxP<P>::mod(i)) + c;
+        r.l[i] = (uint32_t)v & FxP<P>::MASK;
+        c = v >> 29;
+    }
+    int64_t v = (int64_t)a.l[L - 1] - (int64_t)((uint64_t)q * FxP<P>::mod(L - 1)) + c;
+    r.l[L - 1] = (uint32_t)v;
+    return r;
+}
+
+// -p^-1 mod 2^(29 L) as L limbs (Hensel lifting on 32-bit words; host, table setup only)
+template <class P>
+inline Fx<P> fx_neg_p_inverse() {
+    constexpr int L = FxP<P>::L;
+    constexpr int W = (29 * L + 31) / 32;
+    auto mul_lo = [=](const uint32_t* a, const uint32_t* b, uint32_t* r) {
+        uint32_t out[W];
+        uint64_t carry = 0;
+        for (int k = 0; k < W; ++k) {   // column k, accumulated in two halves to stay inside 64 bits
+            uint64_t lo = carry & 0xffffffffull, hi = carry >> 32;
+            for (int i = 0; i <= k; ++i) {
+                const uint64_t pr = (uint64_t)a[i] * b[k - i];
+                lo += pr & 0xffffffffull;
+                hi += pr >> 32;
+            }
+            hi += lo >> 32;
+            out[k] = (uint32_t)lo;
+            carry = hi;
+        }
+        for (int k = 0; k < W; ++k) r[k] = out[k];
+    };
+    uint32_t p[W] = {}, x[W] = {};
+    for (int i = 0; i < P::N; ++i) p[i] = P::mod(i);
+    x[0] = 1;   // p x = 1 mod 2
+    for (int it = 0; it < 10; ++it) {   // x <- x (2 - p x): the number of correct bits doubles
+        uint32_t t[W], u[W];
+        mul_lo(p, x, t);
+        uint32_t borrow = 0;
+        for (int k = 0; k < W; ++k) {   // u = 2 - t
+            const uint64_t v = (uint64_t)(k == 0 ? 2u : 0u) - t[k] - borrow;
+            u[k] = (uint32_t)v;
+            borrow = (uint32_t)(v >> 63);
+        }
+        mul_lo(x, u, t);
+        for (int k = 0; k < W; ++k) x[k] = t[k];
+    }
+    uint32_t neg[W + 1] = {};
+    uint32_t borrow = 0;
+    for (int k = 0; k < W; ++k) {
+        const uint64_t v = (uint64_t)0 - x[k] - borrow;
+        neg[k] = (uint32_t)v;
+        borrow = (uint32_t)(v >> 63);
+    }
+    Fx<P> r;
+    for (int i = 0; i < L; ++i) {
+        const int lo = 29 * i, w = lo >> 5, o = lo & 31;
+        const uint64_t v = (uint64_t)neg[w] | ((uint64_t)neg[w + 1] << 32);
+        r.l[i] = (uint32_t)(v >> o) & FxP<P>::MASK;
+    }
+    return r;
 }
 
 // ---- arkworks-form product on packed operands: the drop-in behind fe_mul ---------------------------

@@ -1,6 +1,7 @@
 // NTT kernels + plan construction (see ntt.hpp for the decomposition).
 #include "ctx.hpp"
 #include "hostinv.hpp"
+#include <cstdlib>
 
 namespace zkt {
 
@@ -30,45 +31,46 @@ ZKT_D void tile_put(uint4* lo, uint4* hi, uint32_t* top, int64_t idx, const Fx<P
 
 ZKT_D uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
-// inner twiddles of a pass in LDS: R/2 entries.  Up to R = 128 they are kept unpacked (limbs, the tile's three-plane
-// layout); from R = 256 on the extra 4 bytes per entry would cost a resident workgroup per CU (4 x 40 KiB is exactly
-// the LDS), so they stay packed and are unpacked at every use.
-template <class P, bool UNPACKED>
+// inner twiddles of a pass in LDS: R/2 entries.  MODE 2 (Shoup): each the pair (w, wq = floor(w 2^261 / p)) of
+// fx_mul_shoup as eighteen 29-bit limbs in the tile's three-plane layout (72 bytes per entry, no Montgomery factor).
+// MODE 1 / 0: the Montgomery form w 2^261 mod p of the earlier rounds (product = fx_mul_inl), as nine limbs (36 bytes) or,
+// MODE 0, as eight packed words unpacked at every use (32 bytes: at R = 256 that keeps a fourth workgroup per CU).
+constexpr int NTT_W_PACKED = 0, NTT_W_LIMBS = 1, NTT_W_SHOUP = 2;
+template <class P, int MODE>
 struct WTile {
     const uint4* lo;
     const uint4* hi;
     const uint32_t* top;
-    ZKT_D Fx<P> get(int e) const {
-        if constexpr (UNPACKED) {
-            return tile_get<P>(lo, hi, top, e);
+    const uint4* qlo;      // the quotient words stay in global memory (three planes of R/2 entries, a few KiB that live in
+    const uint4* qhi;      // the vector L1): with them in LDS as well the tile would cost the fourth workgroup per CU
+    const uint32_t* qtop;
+    // d: the butterfly's difference (limbs <= 2^31.33, value < 16p); returns d * w, normalised, < 3p
+    ZKT_D Fx<P> mul(int e, const Fx<P>& d) const {
+        if constexpr (MODE == NTT_W_SHOUP) {
+            return fx_mul_shoup<P>(d, tile_get<P>(lo, hi, top, e), tile_get<P>(qlo, qhi, qtop, e));
+        } else if constexpr (MODE == NTT_W_LIMBS) {
+            return fx_mul_inl<P>(tile_get<P>(lo, hi, top, e), d);
         } else {
             Fe<P> w;
             const uint4 a = lo[e], b = hi[e];
             w.v[0] = a.x; w.v[1] = a.y; w.v[2] = a.z; w.v[3] = a.w;
             w.v[4] = b.x; w.v[5] = b.y; w.v[6] = b.z; w.v[7] = b.w;
-            return fx_unpack<P>(w);
-        }
-    }
-    ZKT_D static void put(uint4* lo, uint4* hi, uint32_t* top, int e, const Fe<P>& w) {
-        if constexpr (UNPACKED) {
-            tile_put<P>(lo, hi, top, e, fx_unpack<P>(w));
-        } else {
-            lo[e] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
-            hi[e] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
+            return fx_mul_inl<P>(fx_unpack<P>(w), d);
         }
     }
 };
 
-// One radix-2^G DIF step on 2^G elements held in registers (inputs < 2p, limbs normalised).
+// One radix-2^G DIF step on 2^G elements held in registers (inputs < 3p, limbs normalised).
 //   level L: block size m = R >> L; element i sits at row blk*m + i*sub + off, sub = m >> G.
 //   sub-level l pairs (i, i + h), h = 2^(G-1-l); twiddle W_R^(((i & (h-1))*sub + off) << (L + l)).
-// Lazy bounds: at sub-level l the inputs are < 2^(l+1) p; sums double, differences get K = 2^(l+1) + 1
-// multiples of p added and are brought back below 2p by the twiddle product (twiddles are canonical,
-// R'-Montgomery form, so the product needs no more than a * p < R' p).  A difference that feeds a product
-// skips the carry pass altogether (fx_sub_lazy).  In the LAST step of a pass (sub == 1, off == 0) the
-// twiddle index depends on i only: W^0 products are skipped at compile time.
+// Nothing propagates a carry inside a group: sums are limb-wise (limbs < 2^30 after sub-level 0, < 2^31 after 1), a
+// difference that feeds a twiddle product is u + K p - v with K p spread so that no limb goes negative (fx_sub_lazy: the
+// subtrahend normalised, K = 4 >= 3 + 1; fx_sub_lazy_wide<8, 30>: a sub-level-0 result, < 7p with limbs < 2^30), and the
+// product brings it back below 3p with normalised limbs.  In the LAST step of a pass (sub == 1, off == 0) the twiddle
+// index depends on i only and W^0 products are skipped at compile time: those differences take a carry pass.
 template <class P, int G, bool LASTSTEP, class W>
 ZKT_D void dif_group(Fx<P>* x, const W& w, int off, int sub, int L) {
+    static_assert(G == 1 || G == 2, "radix 2 or 4 register groups");
 #pragma unroll
     for (int l = 0; l < G; ++l) {
         const int h = 1 << (G - 1 - l);
@@ -76,18 +78,16 @@ ZKT_D void dif_group(Fx<P>* x, const W& w, int off, int sub, int L) {
         for (int i = 0; i < (1 << G); ++i) {
             if ((i & h) == 0) {
                 const Fx<P> u = x[i], v = x[i + h];
-                x[i] = fx_add<P>(u, v);
+                x[i] = fx_add_lazy<P>(u, v);
                 if (LASTSTEP && (i & (h - 1)) == 0) {   // twiddle is W^0 = 1
-                    if (l == 0) x[i + h] = fx_sub<P, 2>(u, v);
-                    else if (l == 1) x[i + h] = fx_sub<P, 4>(u, v);
-                    else x[i + h] = fx_sub<P, 8>(u, v);
+                    if (l == 0) x[i + h] = fx_sub<P, 4>(u, v);          // < 7p
+                    else x[i + h] = fx_sub<P, 8>(u, v);                  // < 15p
                 } else {
                     Fx<P> d;
-                    if (l == 0) d = fx_sub_lazy<P, 3>(u, v);
-                    else if (l == 1) d = fx_sub_lazy<P, 5>(u, v);
-                    else d = fx_sub_lazy<P, 9>(u, v);
+                    if (l == 0) d = fx_sub_lazy<P, 4>(u, v);             // < 7p, limbs < 3 * 2^29
+                    else d = fx_sub_lazy_wide<P, 8, 30>(u, v);           // < 15p, limbs < 2^31.33
                     const int e = ((i & (h - 1)) * sub + off) << (L + l);
-                    x[i + h] = fx_mul_inl<P>(w.get(e), d);
+                    x[i + h] = w.mul(e, d);
                 }
             }
         }
@@ -114,11 +114,11 @@ ZKT_D void dif_step(uint4* lo, uint4* hi, uint32_t* top, const W& w_inner, int t
 #pragma unroll
         for (int i = 0; i < (1 << G); ++i) x[i] = tile_get<P>(lo, hi, top, (row0 + i * sub) * T + c);
         dif_group<P, G, LASTSTEP>(x, w_inner, off, sub, L);
-        // values that did not end on a twiddle product may have grown to 2^(G+1) p: bring them below 2p
+        // values that did not end on a twiddle product are lazy sums (limbs < 2^31, < 16p): back below 3p, normalised
 #pragma unroll
         for (int i = 0; i < (1 << G); ++i) {
             const bool grown = LASTSTEP || ((i & 1) == 0);
-            tile_put<P>(lo, hi, top, (row0 + i * sub) * T + c, grown ? fx_reduce_small<P>(x[i]) : x[i]);
+            tile_put<P>(lo, hi, top, (row0 + i * sub) * T + c, grown ? fx_reduce_lazy<P>(x[i]) : x[i]);
         }
     }
 }
@@ -156,19 +156,19 @@ ZKT_D void dif_all(uint4* lo, uint4* hi, uint32_t* top, const W& w, int tid) {
 // One pass: R-point transforms of a [R][T] tile.  LAST selects the transposing pass.
 // Tables (w_inner, in_row, tw, out_row) are canonical packed words in R' = 2^261 Montgomery form, the data
 // stay in arkworks' R = 2^256 form: data * table / R' keeps the data's form.
-template <class P, int LOG_R, bool LAST>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
+template <class P, int LOG_R, bool LAST, int MODE>
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass(NttPassArgs a) {
     constexpr int R = 1 << LOG_R;
     constexpr int LOG_T = TILE_LOG - LOG_R;
     constexpr int T = 1 << LOG_T;
     __shared__ uint4 lds_lo[TILE];
     __shared__ uint4 lds_hi[TILE];
     __shared__ uint32_t lds_top[TILE];
-    constexpr bool W_UNPACKED = LOG_R <= 7;
-    typedef WTile<P, W_UNPACKED> WT;
+    typedef WTile<P, MODE> WT;
+    constexpr bool SHOUP = MODE == NTT_W_SHOUP;
     __shared__ uint4 lds_w_lo[R / 2];
     __shared__ uint4 lds_w_hi[R / 2];
-    __shared__ uint32_t lds_w_top[W_UNPACKED ? R / 2 : 1];
+    __shared__ uint32_t lds_w_top[MODE != NTT_W_PACKED ? R / 2 : 1];
 
     const int tid = threadIdx.x;
     // blockIdx.y = polynomial of the batch (uniform: scalar selects, no indexed access to the kernel arguments)
@@ -185,8 +185,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     const Fe<P>* tw = reinterpret_cast<const Fe<P>*>(a.tw);
     const Fe<P>* out_row = reinterpret_cast<const Fe<P>*>(a.out_row);
 
-    for (int i = tid; i < R / 2; i += NTT_THREADS) WT::put(lds_w_lo, lds_w_hi, lds_w_top, i, fe_load<P>(w_inner + i));
-    const WT lds_w{lds_w_lo, lds_w_hi, lds_w_top};
+    for (int i = tid; i < R / 2; i += NTT_THREADS) {
+        if constexpr (SHOUP) {   // six planes of R/2 entries: w (lo, hi, top), then wq
+            const uint4* wl = reinterpret_cast<const uint4*>(a.w_inner_s);
+            tile_put<P>(lds_w_lo, lds_w_hi, lds_w_top, i, tile_get<P>(wl, wl + R / 2, reinterpret_cast<const uint32_t*>(wl + R), i));
+        } else if constexpr (MODE == NTT_W_LIMBS) {
+            tile_put<P>(lds_w_lo, lds_w_hi, lds_w_top, i, fx_unpack<P>(fe_load<P>(w_inner + i)));
+        } else {
+            const Fe<P> w = fe_load<P>(w_inner + i);
+            lds_w_lo[i] = make_uint4(w.v[0], w.v[1], w.v[2], w.v[3]);
+            lds_w_hi[i] = make_uint4(w.v[4], w.v[5], w.v[6], w.v[7]);
+        }
+    }
+    // the table: uint4 w_lo[R/2] | uint4 w_hi[R/2] | u32 w_top[R/2] | (16-byte aligned) uint4 q_lo[R/2] | uint4 q_hi[R/2] | u32 q_top[R/2]
+    const uint4* gq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w_inner_s) + (R / 2) * 36 + ((R / 2) * 36 % 16 ? 16 - (R / 2) * 36 % 16 : 0));
+    const WT lds_w{lds_w_lo, lds_w_hi, lds_w_top, gq, gq + R / 2, reinterpret_cast<const uint32_t*>(gq + R)};
 
     const uint64_t tile = blockIdx.x;
     uint64_t in_base, out_base, tw_base;
@@ -259,7 +272,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
         int k = flat >> LOG_T;
         int rho = (int)bitrev32((uint32_t)k, LOG_R);
         Fx<P> x = tile_get<P>(lds_lo, lds_hi, lds_top, rho * T + c);
-        if (out_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(out_row + k)));
+        if (out_row) x = fx_mul<P>(x, fx_unpack<P>(fe_load<P>(out_row + k)));   // < 2p
+        else if (!a.out_raw) x = fx_cond_sub_p<P>(x);                            // the tile holds values < 3p
         const uint64_t at = out_base + (uint64_t)k * st_k + c;
         if (a.out_raw) {
             uint4* rlo = reinterpret_cast<uint4*>(out_p);
@@ -276,6 +290,24 @@ __global__ void k_table_to_fx(Fe<P>* t, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     fe_store<P>(t + i, fx_pack<P>(fx_cond_sub_p<P>(fx_from_ark<P>(fe_load<P>(t + i)))));
+}
+
+// inner twiddles, arkworks R form -> the pairs of fx_mul_shoup: w as a plain canonical integer and
+// wq = floor(w 2^261 / p) = (w 2^261 - w^) / p with w^ = w 2^261 mod p, an exact division: wq = w^ * (-p^-1) mod 2^261
+template <class P>
+__global__ void k_table_to_shoup(const Fe<P>* t, void* out, uint64_t n, Fx<P> npinv) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe<P> x = fe_load<P>(t + i);
+    const Fx<P> w = fx_unpack<P>(fe_from_mont<P>(x));
+    const Fx<P> what = fx_cond_sub_p<P>(fx_from_ark<P>(x));
+    const Fx<P> wq = fx_mul_low<P>(what, npinv);
+    // two groups of three planes (the LDS tile's layout), the second 16-byte aligned
+    const uint64_t plane = n * 36, second = (plane + 15) & ~(uint64_t)15;
+    uint4* wl = reinterpret_cast<uint4*>(out);
+    tile_put<P>(wl, wl + n, reinterpret_cast<uint32_t*>(wl + 2 * n), (int64_t)i, w);
+    uint4* ql = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + second);
+    tile_put<P>(ql, ql + n, reinterpret_cast<uint32_t*>(ql + 2 * n), (int64_t)i, wq);
 }
 
 // Whole transform in one workgroup for n <= 1024 (plumbing sizes; not a performance path).
@@ -519,6 +551,18 @@ static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>&
         if ((rc = alloc_table(c, pl, &pl.out_row, (size_t)1 << pl.log_r[p - 1]))) return rc;
         if ((rc = gen_pow<P>(c, pl.out_row, (uint64_t)1 << pl.log_r[p - 1], gp, one))) return rc;
     }
+    // butterfly twiddles as Shoup pairs (from the arkworks form, before it is converted below)
+    {
+        const Fx<P> npinv = fx_neg_p_inverse<P>();
+        for (int i = 0; i < p; ++i) {
+            const uint64_t cnt = (uint64_t)1 << (pl.log_r[i] - 1);
+            if ((rc = dev_alloc(c, &pl.w_inner_s[i], cnt * 72 + 16))) return rc;
+            pl.table_bytes += cnt * 72 + 16;
+            hipLaunchKernelGGL(k_table_to_shoup<P>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
+                               (const Fe<P>*)pl.w_inner[i], pl.w_inner_s[i], cnt, npinv);
+            ZKT_HIP(c, hipGetLastError());
+        }
+    }
     // the pass kernels multiply lazily reduced 29-bit-limb data by these tables: keep them in R' form
     for (int i = 0; i < p; ++i)
         if ((rc = table_to_fx<P>(c, pl.w_inner[i], (uint64_t)1 << (pl.log_r[i] - 1)))) return rc;
@@ -534,15 +578,39 @@ static int build_plan(zkt_ctx* c, int log_n, int inverse, int coset, NttPlan<P>&
     return 0;
 }
 
+// Which form the butterfly twiddles of a radix take (WTile).  Shoup pairs save 28 of 171 multiply-adds and the m-chain
+// per product; at R >= 256 their 72 bytes per entry cost the fourth resident workgroup per CU (46 KiB of LDS instead of
+// 40), which the A/B build can trade back (ZKT_NTT_MONT_FROM = first log2 radix that keeps the Montgomery form).
+static int ntt_mode_for(int log_r) {
+    int mont_from = 10;   // every radix uses Shoup pairs
+    if (const char* e = exp_env("ZKT_NTT_MONT_FROM")) mont_from = atoi(e);
+    if (log_r < mont_from) return NTT_W_SHOUP;
+    return log_r <= 7 ? NTT_W_LIMBS : NTT_W_PACKED;
+}
+
+template <class P, bool LAST, int LOG_R>
+static void launch_pass_r(zkt_ctx* c, const dim3& grid, const NttPassArgs& a) {
+    const int mode = ntt_mode_for(LOG_R);
+    if (mode == NTT_W_SHOUP) {
+        hipLaunchKernelGGL((k_ntt_pass<P, LOG_R, LAST, NTT_W_SHOUP>), grid, dim3(NTT_THREADS), 0, c->stream, a);
+        return;
+    }
+#if defined(ZKT_EXPERIMENTS)
+    hipLaunchKernelGGL((k_ntt_pass<P, LOG_R, LAST, (LOG_R <= 7 ? NTT_W_LIMBS : NTT_W_PACKED)>), grid, dim3(NTT_THREADS), 0, c->stream, a);
+#else
+    hipLaunchKernelGGL((k_ntt_pass<P, LOG_R, LAST, NTT_W_SHOUP>), grid, dim3(NTT_THREADS), 0, c->stream, a);
+#endif
+}
+
 template <class P, bool LAST>
 static void launch_pass(zkt_ctx* c, int log_r, unsigned blocks, unsigned nb, const NttPassArgs& a) {
     const dim3 grid(blocks, nb);
     switch (log_r) {
-        case 5: hipLaunchKernelGGL((k_ntt_pass<P, 5, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
-        case 6: hipLaunchKernelGGL((k_ntt_pass<P, 6, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
-        case 7: hipLaunchKernelGGL((k_ntt_pass<P, 7, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((k_ntt_pass<P, 8, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL((k_ntt_pass<P, 9, LAST>), grid, dim3(NTT_THREADS), 0, c->stream, a); break;
+        case 5: launch_pass_r<P, LAST, 5>(c, grid, a); break;
+        case 6: launch_pass_r<P, LAST, 6>(c, grid, a); break;
+        case 7: launch_pass_r<P, LAST, 7>(c, grid, a); break;
+        case 8: launch_pass_r<P, LAST, 8>(c, grid, a); break;
+        default: launch_pass_r<P, LAST, 9>(c, grid, a); break;
     }
 }
 
@@ -595,6 +663,7 @@ static int ntt_run_batch_t(zkt_ctx* c, int log_n, int inverse, int coset, int nb
             a.in_len[y] = (i == 0) ? (uint64_t)in_len[yy] : N;
         }
         a.w_inner = pl.w_inner[i];
+        a.w_inner_s = pl.w_inner_s[i];
         a.in_row = (i == 0) ? pl.in_row : nullptr;
         a.tw = pl.tw[i];
         a.out_row = last ? pl.out_row : nullptr;

@@ -25,7 +25,8 @@ constexpr int NTT_MAX_BATCH = 4;   // transforms of one plan issued as ONE launc
 struct NttPassArgs {
     const void* in[NTT_MAX_BATCH];    // Fe* (raw passes: polynomial y lives at in[0] + y * 36 * raw_n bytes)
     void* out[NTT_MAX_BATCH];         // Fe*
-    const void* w_inner;   // R/2 inner twiddles W_R^j
+    const void* w_inner;   // R/2 inner twiddles W_R^j, Montgomery form (packed words)
+    const void* w_inner_s; // the same as (w, floor(w 2^261 / p)) pairs of 9 + 9 limbs (fx_mul_shoup)
     const void* in_row;    // optional R-entry input row scale (forward coset, pass 1)
     const void* tw;        // optional boundary twiddles (row-shared or tile-shaped)
     const void* out_row;   // optional R-entry output row scale (inverse coset, last pass)
@@ -34,7 +35,7 @@ struct NttPassArgs {
     uint32_t log_s;        // non-last: log2 of the inner stride S (columns); last: unused
     uint32_t log_r1;       // last: log2 R1
     uint32_t log_mid;      // last: log2 (N / (R1*Rp))
-    // Between passes the data stay as 29-bit limbs, lazily reduced (< 2p), in three planes of N entries (limbs 0-3,
+    // Between passes the data stay as 29-bit limbs, lazily reduced (< 3p), in three planes of N entries (limbs 0-3,
     // limbs 4-7, limb 8: the LDS tile's layout, 36 N bytes at raw_base): no packing, reduction or unpacking there.
     uint32_t in_raw, out_raw;
     uint64_t raw_n;        // N (plane stride)
@@ -47,6 +48,7 @@ struct NttPlan {
     int npass = 0;            // 0: single-workgroup kernel (log_n <= 10)
     int log_r[3] = {0, 0, 0};
     void* w_inner[3] = {nullptr, nullptr, nullptr};
+    void* w_inner_s[3] = {nullptr, nullptr, nullptr};
     void* in_row = nullptr;   // pass 1 (forward coset)
     void* tw[3] = {nullptr, nullptr, nullptr};  // tw[i] consumed by pass i (i >= 1)
     void* out_row = nullptr;  // last pass (inverse coset)
