@@ -471,6 +471,15 @@ int zkt_debug_pairing_selftest(int curve_id);
  * Montgomery words.  Whole-coset (single-GPU) circuits only. */
 int zkt_debug_quotient(zkt_ctx* ctx, const uint64_t* challenges, const uint64_t* const* wit, const uint64_t* pi_pos,
                        const uint64_t* pi_vals, size_t n_pi, uint64_t* out);
+/* The two grand products alone over the loaded circuit's permutation and domain (rows a8 / a9: compute_z1_poly's and
+ * compute_z2_poly's evaluation vectors, permutation/mod.rs:181-254, lookup/mod.rs:94-151), through the launches round 3 of
+ * the prover makes.  challenges: beta gamma delta epsilon (4 x 4 words); vectors: a b c f t h1 h2, n elements each, host;
+ * out_z1 / out_z2: n elements each.  Montgomery words. */
+int zkt_debug_grand_products(zkt_ctx* ctx, const uint64_t* challenges, const uint64_t* const* vectors, uint64_t* out_z1,
+                             uint64_t* out_z2);
+/* kzg10's witness polynomial alone (row a12): out[0 .. len - 1) = (p(X) - p(z)) / (X - z) for the len <= n + 8 coefficients
+ * p, as the prover computes it (scaled suffix sums).  Host pointers, Montgomery words. */
+int zkt_debug_open_witness(zkt_ctx* ctx, const uint64_t* coeffs, size_t len, const uint64_t* z4, uint64_t* out);
 
 #ifdef __cplusplus
 }

@@ -453,3 +453,88 @@ def test_withdraw_circuit_at_the_clis_default_size(cvname, width, inputs, height
     ctx.free(d_vars)
     g.close()
     ctx.close()
+
+
+def test_config3_the_withdraw_circuit_itself_at_2_20():
+    """BASELINE.json configs[3] literally: WithdrawCircuit<Fr, u64, _, Bn254x5, INPUTS = 8, HEIGHT = 64>
+    (circuits/src/withdraw.rs:57-150; 1 019 498 gates, n = 2^20, 12 public inputs, 538 Poseidon gadgets of 1888 gates) on
+    BN254 -- the workload of bench.py, here under pytest.  Rows laid out by tools/withdraw_workload.py (pinned row for row
+    against the oracle composer at smaller shapes in tests/test_withdraw_workload.py), the hashes' 1 015 744 variables made on
+    the device (PoseidonGadget.fill), the prover handed the variable map and the wire index vectors in HBM.  Checked: the
+    wire values equal the oracle composer's own synthesis of the same withdrawal (oracle/composer.py, gate by gate), which
+    satisfies every gate; the proof bytes equal the CPU oracle's array prover (oracle/fastplonk.py) on the same SRS, witness
+    and blinders."""
+    import os
+    import sys
+    import zkt_plonk_amd as z
+    from oracle import composer as OC, fastplonk as FP
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import withdraw_workload as WW
+    cv = F.BN254
+    p = cv.fr.p
+    log_n, width, inputs, height = 20, 5, 8, 64
+    n = 1 << log_n
+    hs = WW.reference_hasher(p, width)
+    inst = WW.make_instance(hs, inputs, height, seed=0x5EED)
+    lay = WW.layout(hs, inst)
+    gates, n_vars = lay.n_gates, len(lay.values)
+    assert gates == 1019498 and len(lay.pi) == 12 and len(lay.hash_calls) == 538 and hs.per_hash == 1888
+    tau = 0x5EED5EED1234567890ABCDEF % p
+    ctx = z.Context(cv.name, 0)
+    try:
+        ctx.srs_generate(tau, n + 8)
+        srs = ctx.srs_download(0, n + 8)
+        sel = WW.setup_vectors(lay, log_n, 5)
+        evals = {name: K.fr_to_mont(cv, sel[name]) for name in z.PK_ORDER}
+        del sel
+        prover, commits = z.GpuProver.setup(ctx, log_n, evals)
+        L = cv.fq.limbs64
+        rinv = pow(1 << (64 * L), -1, cv.fq.p)
+        vk_pts = {name: (None if inf else (sum(int(v) << (64 * i) for i, v in enumerate(xy[:L])) * rinv % cv.fq.p,
+                                           sum(int(v) << (64 * i) for i, v in enumerate(xy[L:])) * rinv % cv.fq.p))
+                  for name, (xy, inf) in commits.items()}
+        to_mont = lambda vals: K.fr_to_mont(cv, vals)
+        gadget = z.PoseidonGadget(ctx, hs.width, hs.half_full, hs.partial, to_mont(hs.rc),
+                                  to_mont([x for row in hs.mds for x in row]), to_mont([hs.tag])[0])
+        assert gadget.vars_per_hash == hs.per_hash
+        for base, ins in lay.hash_calls:
+            gadget.hash(base, ins)
+        gadget.stage()
+        d_vars = ctx.alloc(n_vars * 32)
+        ctx.upload(d_vars, to_mont(lay.values))                 # zeros where the device writes
+        assert gadget.fill(d_vars, n_vars) == 2                 # the leaf hashes wait for the commitment hashes
+        idx = [np.asarray(w, dtype=np.uint32) for w in lay.w]
+        d_idx = []
+        for x in idx:
+            d = ctx.alloc(4 * len(x))
+            ctx.upload(d, x)
+            d_idx.append(d)
+        full = np.concatenate([ctx.download(d_vars, (n_vars, 4)), np.zeros((1, 4), np.uint64)])
+        wires = [full[np.where(x == WW.ZERO, n_vars, x)] for x in idx]
+        # the checker's own synthesis of the same withdrawal: satisfied, and the same wire values
+        prm = OC.PoseidonParams(p, hs.width, hs.half_full, hs.partial, hs.rc, hs.mds, hs.tag)
+        cs = OC.Composer(cv, inst["ident_set"], 1024)
+        OC.withdraw_synthesize(cs, prm, inst["secrets"], inst["identifiers"], inst["amounts"], inst["poes"], inst["root"],
+                               inst["new_secret"], inst["new_identifier"], inst["withdraw_amount"])
+        assert cs.n_gates == gates == OC.withdraw_gate_count(prm, inputs, height) and cs.check_satisfied()
+        for got_w, want_w in zip(wires, cs.wire_evals(cs.n_gates)):
+            assert np.array_equal(got_w, K.fr_to_mont(cv, want_w))
+        assert dict(cs.pi) == dict(lay.pi)
+        del cs
+        # proof bytes against the CPU oracle
+        table = to_mont(inst["ident_set"])
+        pi_pos = sorted(lay.pi)
+        blinders = field_elems(p, 2020, P.NUM_BLINDERS)
+        prep = ctx.prepare_vars_dev(d_vars, n_vars, d_idx[0], d_idx[1], d_idx[2], gates, table, pi_pos,
+                                    to_mont([lay.pi[k] for k in pi_pos]), to_mont(blinders))
+        tr = z.seed_transcript(z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=8 * L), n, vk_pts)
+        got = ctx.prove_prepared(prep, tr)
+        assert ctx.lagrange_info()["log_n"] == log_n           # h1 / h2 / z2 went through the Lagrange-basis table
+        keys = FP.setup(cv, srs, log_n, evals, commitments=False)
+        keys.commits = dict(vk_pts)
+        vk = keys.verifier_key(cv, lay.pi.keys())
+        want = FP.prove(cv, srs, keys, wires[0], wires[1], wires[2], table, dict(lay.pi), P.new_seeded_transcript(cv, vk), blinders)
+        assert got == want and len(got) == 802
+        gadget.close()
+    finally:
+        ctx.close()

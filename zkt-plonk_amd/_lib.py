@@ -867,6 +867,29 @@ class Context:
         self.check(self._L.zkt_debug_fr_mul(self._h, u64p(a), u64p(b), a.shape[0], u64p(out)))
         return out
 
+    def debug_grand_products(self, n: int, challenges, vectors):
+        """z1, z2 evaluation vectors (zkt_debug_grand_products): challenges (4, 4) beta gamma delta epsilon; vectors: seven
+        (n, 4) host arrays a b c f t h1 h2."""
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(4, 4)
+        keep = [np.ascontiguousarray(w, dtype=np.uint64).reshape(n, 4) for w in vectors]
+        assert len(keep) == 7
+        ptrs = (ctypes.c_void_p * 7)(*[w.ctypes.data for w in keep])
+        z1, z2 = np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64)
+        self._L.zkt_debug_grand_products.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_void_p),
+                                                     ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        self.check(self._L.zkt_debug_grand_products(self._h, u64p(ch), ptrs, u64p(z1), u64p(z2)))
+        return z1, z2
+
+    def debug_open_witness(self, coeffs, z) -> np.ndarray:
+        """(p(X) - p(z)) / (X - z) (zkt_debug_open_witness): coeffs (len, 4), z (4,), Montgomery words."""
+        p_ = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
+        out = np.empty((p_.shape[0] - 1, 4), dtype=np.uint64)
+        self._L.zkt_debug_open_witness.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t,
+                                                   ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        self.check(self._L.zkt_debug_open_witness(self._h, u64p(p_), p_.shape[0], u64p(zz), u64p(out)))
+        return out
+
     def debug_quotient(self, n: int, challenges, wit, pi_pos=(), pi_vals=None) -> np.ndarray:
         """The quotient kernel alone over the loaded circuit (zkt_debug_quotient): challenges (5, 4) alpha beta gamma
         delta epsilon; wit: nine (4n, 4) host arrays a b c pi z1 z2 t h1 h2 (wit[3] may be None with public inputs

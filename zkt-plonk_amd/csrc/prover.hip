@@ -1151,6 +1151,49 @@ struct VtableAdapter : HostTranscript {
 };
 }  // namespace zkt
 
+// The two grand products alone (rows a8 / a9 of SURVEY.md section 8: permutation/mod.rs:181-254, lookup/mod.rs:94-151) over
+// the loaded circuit's sigma evaluations and domain: the same launches round 3 of the prover makes (term kernels, prefix
+// and suffix product scans, ONE host inversion for both denominators, z_combine), on caller-supplied vectors.
+template <class C>
+static int debug_grand_products_t(zkt_ctx* c, const uint64_t* ch, const uint64_t* const* v, uint64_t* out_z1, uint64_t* out_z2) {
+    using R = typename C::Fr;
+    using F = Fe<R>;
+    CircuitState& S = *c->circuit;
+    const size_t n = S.n;
+    void* dst[7] = {S.ev[0], S.ev[1], S.ev[2], S.ev[4], S.ev[3], S.ev[5], S.ev[6]};   // a b c f t h1 h2
+    for (int k = 0; k < 7; ++k) ZKT_HIP(c, hipMemcpyAsync(dst[k], v[k], n * 32, hipMemcpyHostToDevice, c->stream));
+    ZTermsArgs za{};
+    za.a = S.ev[0]; za.b = S.ev[1]; za.c = S.ev[2];
+    za.s1 = S.sigma_ev[0]; za.s2 = S.sigma_ev[1]; za.s3 = S.sigma_ev[2]; za.roots = S.roots;
+    za.f = S.ev[4]; za.t = S.ev[3]; za.h1 = S.ev[5]; za.h2 = S.ev[6];
+    za.num = S.sc[0]; za.den = S.sc[1]; za.n = n;
+    memcpy(za.beta, ch, 32); memcpy(za.gamma, ch + 4, 32); memcpy(za.delta, ch + 8, 32); memcpy(za.epsilon, ch + 12, 32);
+    void* pn2 = S.wcos[W_Z1];
+    void* sd2 = (char*)S.wcos[W_Z1] + n * 32;
+    F* pin = (F*)S.pinned;
+    int rc;
+    if ((rc = z1_terms(c, za))) return rc;
+    if ((rc = scan_mul(c, S.sc[0], S.sc[2], n, false, S.scan_tmp))) return rc;
+    if ((rc = scan_mul(c, S.sc[1], S.sc[3], n, true, S.scan_tmp))) return rc;
+    if ((rc = z2_terms(c, za))) return rc;
+    if ((rc = scan_mul(c, S.sc[0], pn2, n, false, S.scan_tmp))) return rc;
+    if ((rc = scan_mul(c, S.sc[1], sd2, n, true, S.scan_tmp))) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(pin, S.sc[3], 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipMemcpyAsync(pin + 1, sd2, 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    if (fe_is_zero<R>(pin[0])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the permutation grand product");
+    if (fe_is_zero<R>(pin[1])) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "zero denominator in the lookup grand product");
+    const F d1 = pin[0], d2 = pin[1];
+    const F inv12 = fe_inv_host<R>(fe_mul<R>(d1, d2));
+    const F inv1 = fe_mul<R>(inv12, d2), inv2 = fe_mul<R>(inv12, d1);
+    if ((rc = z_combine(c, S.sc[2], S.sc[3], inv1.v, S.ev[7], n))) return rc;
+    if ((rc = z_combine(c, pn2, sd2, inv2.v, S.sc[0], n))) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(out_z1, S.ev[7], n * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipMemcpyAsync(out_z2, S.sc[0], n * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
 extern "C" {
 
 zkt_transcript* zkt_transcript_new(int kind, const char* label) {
@@ -1396,6 +1439,50 @@ int zkt_debug_quotient(zkt_ctx* c, const uint64_t* challenges, const uint64_t* c
     dev_free(c, d_out);
     dev_free(c, d_tab);
     return rc;
+}
+
+int zkt_debug_grand_products(zkt_ctx* c, const uint64_t* challenges, const uint64_t* const* vectors, uint64_t* out_z1,
+                             uint64_t* out_z2) {
+    if (!c || !challenges || !vectors || !out_z1 || !out_z2) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    for (int k = 0; k < 7; ++k)
+        if (!vectors[k]) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null vector");
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    (void)hipSetDevice(c->device);
+    c->circuit->prefetch_stage = 0;   // the work buffers are shared with an announced proof's early rounds
+    if (c->curve == ZKT_CURVE_BN254) return debug_grand_products_t<Bn254Curve>(c, challenges, vectors, out_z1, out_z2);
+    return debug_grand_products_t<Bls381Curve>(c, challenges, vectors, out_z1, out_z2);
+}
+
+// kzg10::compute_witness_polynomial alone (row a12: the division of prove.rs:381-451's aggregated polynomial by X - z)
+int zkt_debug_open_witness(zkt_ctx* c, const uint64_t* coeffs, size_t len, const uint64_t* z4, uint64_t* out) {
+    if (!c || !coeffs || !z4 || !out) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    CircuitState& S = *c->circuit;
+    if (len < 2 || len > S.n + 8) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "2 .. n + 8 coefficients");
+    (void)hipSetDevice(c->device);
+    c->circuit->prefetch_stage = 0;
+    uint32_t z[8], zi[8];
+    memcpy(z, z4, 32);
+    bool zero = true;
+    for (int i = 0; i < 8; ++i) zero = zero && z[i] == 0;
+    if (zero) return set_err(c, ZKT_ERR_ZERO_DENOMINATOR, "evaluation point is zero");
+    if (c->curve == ZKT_CURVE_BN254) {
+        Fe<Bn254Fr> x;
+        memcpy(x.v, z, 32);
+        x = fe_inv_host<Bn254Fr>(x);
+        memcpy(zi, x.v, 32);
+    } else {
+        Fe<Bls381Fr> x;
+        memcpy(x.v, z, 32);
+        x = fe_inv_host<Bls381Fr>(x);
+        memcpy(zi, x.v, 32);
+    }
+    ZKT_HIP(c, hipMemcpyAsync(S.sc[0], coeffs, len * 32, hipMemcpyHostToDevice, c->stream));
+    int rc = open_witness(c, S.sc[0], len, z, zi, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw);
+    if (rc) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(out, S.sc[3], (len - 1) * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
 }
 
 int zkt_prove_set_next(zkt_ctx* c, const zkt_prove_inputs* next) {
