@@ -40,7 +40,11 @@ int zkt_comm_rccl_create(const uint8_t id[ZKT_COMM_RCCL_UNIQUE_ID_BYTES], int ra
  *   on_device = 1: ncclAllGather of `bytes` chars per rank on `stream`, then the stream is synchronised (the vtable's
  *                  contract: complete on return).  send == recv + rank * bytes is RCCL's in-place form and is passed
  *                  through; any other overlap of send with recv is staged through a private device buffer.
- *   on_device = 0: host buffers, staged through a private device buffer on a private stream. */
+ *   on_device = 0: host buffers, staged through a private device buffer on a private stream.
+ * all_gather_async(d_send, d_recv, bytes, stream): the device form without the synchronisation: enqueued on `stream` and
+ * left there (zkt_comm_vtable's optional stream-ordered entry; the library then pipelines the quotient exchange).
+ * A local HIP / RCCL failure inside an exchange aborts the communicator (ncclCommAbort) so that the peers' collectives
+ * fail instead of waiting for this rank; every later call on it fails.  One host thread at a time per communicator. */
 int zkt_comm_rccl_vtable(zkt_comm_rccl* comm, zkt_comm_vtable* out);
 /* ncclCommDestroy + release of the staging buffers. */
 void zkt_comm_rccl_destroy(zkt_comm_rccl* comm);

@@ -97,14 +97,22 @@ const char* zkt_version(void);
  * thread and gloo ranks on one GPU up to BLS12-381 n = 2^22 x 8 ranks.
  * all_gather: `bytes` per rank, results in rank order; on_device = 0: host pointers;
  * on_device = 1 (only if device_buffers != 0): device pointers, the library has synchronised `hip_stream` before the
- * call and the exchange must be complete when the callback returns.  Returns 0 on success. */
+ * call and the exchange must be complete when the callback returns.  Returns 0 on success.
+ * all_gather_async (optional, may be NULL; needs device_buffers != 0): device pointers; the collective is ENQUEUED on
+ * `hip_stream` behind the work already there and the callback returns without waiting for it -- the library never
+ * synchronises the host around it.  With it the quotient exchange of round 4 goes out in ZKT_QUOTIENT_CHUNKS pieces on a
+ * stream of its own, each behind the kernel that produced the piece, so that the collective of one piece travels while
+ * the next is computed, and the host is not blocked at any exchange of device data.  Without it the library falls back
+ * to the blocking callback (one whole exchange after the quotient pass). */
 typedef struct {
     void* user;
     int rank;
     int world;               /* 1, 2, 4 or 8 */
     int device_buffers;      /* 0: device exchanges are staged through pinned host memory by the library */
     int (*all_gather)(void* user, const void* send, void* recv, size_t bytes, int on_device, void* hip_stream);
+    int (*all_gather_async)(void* user, const void* d_send, void* d_recv, size_t bytes, void* hip_stream);
 } zkt_comm_vtable;
+#define ZKT_QUOTIENT_CHUNKS 4
 /* Attach (or, with NULL / world = 1, detach) the communicator.  Must precede zkt_srs_load_slice / zkt_circuit_load /
  * zkt_circuit_setup of the sharded proof: keys are laid out for the rank's share. */
 int zkt_ctx_set_comm(zkt_ctx* ctx, const zkt_comm_vtable* comm);

@@ -23,6 +23,8 @@ pub struct ZktCommVtable {
     pub world: c_int,
     pub device_buffers: c_int,
     pub all_gather: extern "C" fn(*mut c_void, *const c_void, *mut c_void, usize, c_int, *mut c_void) -> c_int,
+    /// optional stream-ordered form for device buffers (None: the library uses the blocking callback)
+    pub all_gather_async: Option<extern "C" fn(*mut c_void, *const c_void, *mut c_void, usize, *mut c_void) -> c_int>,
 }
 
 #[repr(C)]
@@ -88,6 +90,8 @@ extern "C" {
 }
 
 /// include/zkt_comm_rccl.h: the optional RCCL transport (libzkt_comm_rccl.so), INTEGRATION.md section 3c
+/// Behind the `rccl` cargo feature: a host without librccl builds and links the shim without it.
+#[cfg(feature = "rccl")]
 #[link(name = "zkt_comm_rccl")]
 extern "C" {
     pub fn zkt_comm_rccl_unique_id(out: *mut u8) -> c_int;

@@ -63,8 +63,10 @@ def sharded():
     a, b, c = (K.fr_to_mont(cv, w) for w in cs.wire_evals(cs.n_gates))
     pos = sorted(cs.pi)
     job = (a, b, c, K.fr_to_mont(cv, cs.table), pos, K.fr_to_mont(cv, [cs.pi[i] for i in pos]), K.fr_to_mont(cv, blinders))
-    for world in (2, 4):
-        group = par.RcclLocalGroup(world, 0)
+    for world, use_async in ((2, False), (2, True), (4, True)):
+        # use_async: the communicator offers zkt_comm_vtable::all_gather_async, so the quotient exchange goes out in
+        # ZKT_QUOTIENT_CHUNKS pieces on the library's communication stream (same bytes, more calls)
+        group = par.RcclLocalGroup(world, 0, use_async=use_async)
         comms = [group.comm(r) for r in range(world)]
         out = [None] * world
         ths = [threading.Thread(target=sharded_rank_job, args=(z, par, comms[r], cv, n, srs_arr, evals, vk, [job], out, r, world, True))
@@ -77,8 +79,10 @@ def sharded():
             assert not isinstance(out[r], BaseException) and out[r] is not None, out[r]
             proofs, (calls, sent), (setup_calls, setup_sent) = out[r]
             assert proofs == [want], (world, r)
-            assert calls - setup_calls == 5 and sent - setup_sent == sharded_exchange_bytes(cv, n, world, 1)
-            assert comms[r].device_calls >= 1, "the quotient exchange must have taken the device branch"
+            pieces = 4 if use_async else 1                          # ZKT_QUOTIENT_CHUNKS
+            assert calls - setup_calls == 4 + pieces and sent - setup_sent == sharded_exchange_bytes(cv, n, world, 1)
+            assert comms[r].device_calls >= pieces, "the quotient exchange must have taken the device branch"
+            assert comms[r].async_calls == (pieces if use_async else 0)
         for cm in comms:
             cm.close()
     print("RCCL SHARDED OK", flush=True)

@@ -54,6 +54,8 @@ def test_rccl_transport_library_exports_its_header():
     libzkt_comm_rccl.so, which links RCCL and the HIP runtime and nothing of PyTorch; the main library links no transport."""
     import re
     import subprocess
+    from conftest import rccl_transport_or_skip
+    rccl_transport_or_skip()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = os.path.join(root, "include", "zkt_comm_rccl.h")
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)

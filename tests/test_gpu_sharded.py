@@ -147,6 +147,8 @@ def test_rccl_transport_of_the_c_abi(leg):
     of the sharded prover passes device pointers through capi.hip's device branch into a real ncclAllGather on the context's
     stream (bytes == the CPU oracle's proof, exchange counts and sizes as designed).  In a process of its own, without
     torch: RCCL and HIP are /opt/rocm's, as in a Rust host.  More than one RCCL rank remains UNVERIFIED ON HARDWARE."""
+    from conftest import rccl_transport_or_skip
+    rccl_transport_or_skip()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZKT_SYSTEM_ROCM="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), leg], env=env, capture_output=True,
                        text=True, timeout=900)

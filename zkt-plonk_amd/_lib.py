@@ -118,10 +118,14 @@ ALL_GATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_int, ctypes.c_void_p)
 
 
+ALL_GATHER_ASYNC_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
 class CommVtable(ctypes.Structure):
-    """zkt_comm_vtable (include/zkt_plonk.h): the caller's all-gather for a proof sharded across GPUs."""
+    """zkt_comm_vtable (include/zkt_plonk.h): the caller's all-gather for a proof sharded across GPUs; all_gather_async
+    (optional) is its stream-ordered form for device buffers."""
     _fields_ = [("user", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
-                ("device_buffers", ctypes.c_int), ("all_gather", ALL_GATHER_CB)]
+                ("device_buffers", ctypes.c_int), ("all_gather", ALL_GATHER_CB), ("all_gather_async", ALL_GATHER_ASYNC_CB)]
 
 
 def shard_range(total: int, rank: int, world: int):

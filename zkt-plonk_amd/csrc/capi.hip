@@ -100,6 +100,19 @@ int comm_all_gather_dev(zkt_ctx* c, const void* d_send, void* d_recv, size_t byt
     return ZKT_OK;
 }
 
+bool comm_async_available(const zkt_ctx* c) {
+    return c->sharded() && c->comm.vt.device_buffers && c->comm.vt.all_gather_async != nullptr;
+}
+// stream-ordered exchange of device data through the communicator's optional asynchronous entry: no host wait on either side
+int comm_all_gather_async(zkt_ctx* c, const void* d_send, void* d_recv, size_t bytes, hipStream_t st) {
+    if (!comm_async_available(c)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "communicator without all_gather_async");
+    ++c->comm.calls;
+    c->comm.bytes += bytes;
+    if (c->comm.vt.all_gather_async(c->comm.vt.user, d_send, d_recv, bytes, (void*)st))
+        return set_err(c, ZKT_ERR_COMM, "communicator: all_gather_async failed");
+    return ZKT_OK;
+}
+
 static hipEvent_t prof_event(zkt_ctx* c) {
     if (!c->event_pool.empty()) {
         hipEvent_t e = c->event_pool.back();

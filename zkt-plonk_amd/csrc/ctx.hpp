@@ -97,6 +97,9 @@ struct ProfScope {
 // _dev: device buffers, ordered after everything enqueued on the context's stream, complete on return
 int comm_all_gather_host(zkt_ctx* c, const void* send, void* recv, size_t bytes);
 int comm_all_gather_dev(zkt_ctx* c, const void* d_send, void* d_recv, size_t bytes);
+// the communicator's optional stream-ordered entry (zkt_comm_vtable::all_gather_async): enqueued on `st`, no host wait
+bool comm_async_available(const zkt_ctx* c);
+int comm_all_gather_async(zkt_ctx* c, const void* d_send, void* d_recv, size_t bytes, hipStream_t st);
 
 // grows *p to at least `bytes`
 int ensure_buffer(zkt_ctx* c, void** p, size_t* cur, size_t bytes);

@@ -157,7 +157,7 @@ ZKT_D void dif_all(uint4* lo, uint4* hi, uint32_t* top, const W& w, int tid) {
 // Tables (w_inner, in_row, tw, out_row) are canonical packed words in R' = 2^261 Montgomery form, the data
 // stay in arkworks' R = 2^256 form: data * table / R' keeps the data's form.
 template <class P, int LOG_R, bool LAST, int MODE>
-__global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass(NttPassArgs a) {
+__global__ __launch_bounds__(NTT_THREADS, (LOG_R <= 7 ? 4 : 3)) void k_ntt_pass(NttPassArgs a) {   // workgroups per CU the LDS allows
     constexpr int R = 1 << LOG_R;
     constexpr int LOG_T = TILE_LOG - LOG_R;
     constexpr int T = 1 << LOG_T;

@@ -350,6 +350,7 @@ struct QuotientDev {
     FxArg gamma, epsilon, eopd;                                                    // A
     FxArg zh_inv[4];                                                               // H
     uint64_t n4;
+    uint64_t first, count;   // the points this launch covers
     const uint32_t* pi_tab;
     uint32_t n_pi_direct;
     uint32_t G, cls, next_off;
@@ -367,8 +368,8 @@ template <class P>
 __global__ __launch_bounds__(256) void k_quotient(QuotientDev q) {
     static_assert(FxP<P>::L == 9, "scalar field limbs");
     typedef Fx<P> X;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= q.n4) return;
+    const uint64_t i = q.first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.first + q.count) return;
     // "omega-next": global index + 4, i.e. entry i + next_off of the (possibly neighbouring) class, wrapping
     const uint64_t j = (i + q.next_off < q.n4) ? i + q.next_off : i + q.next_off - q.n4;
 #define LD(ptr, idx) fx_unpack<P>(fe_load<P>((const Fe<P>*)(ptr) + (idx)))   // canonical, < p
@@ -861,7 +862,10 @@ template <class P> static int quotient_t(zkt_ctx* c, const QuotientArgs& a) {
     }
     if (a.pi_tab && a.n_pi_direct > (uint32_t)QUOTIENT_PI_DIRECT_MAX)
         return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "too many direct public inputs");
-    hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(a.n4)), dim3(256), 0, c->stream, q);
+    q.first = a.first;
+    q.count = a.count ? a.count : a.n4 - a.first;
+    if (q.first + q.count > a.n4) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "quotient range outside the vectors");
+    hipLaunchKernelGGL(k_quotient<P>, dim3(nblocks(q.count)), dim3(256), 0, c->stream, q);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
@@ -876,20 +880,27 @@ int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a) { ZKT_DISPATCH(c, quot
 
 // after the all-gather of a sharded proof: class-major -> natural order of the 4n coset
 template <class P>
-__global__ void k_interleave(const Fe<P>* in, Fe<P>* out, uint64_t n4, uint32_t log_g) {
+__global__ void k_interleave(const Fe<P>* in, Fe<P>* out, uint64_t n4, uint32_t log_g, uint64_t piece) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // natural index: coalesced writes
     if (t >= n4) return;
     const uint64_t cls = t & ((1u << log_g) - 1), i = t >> log_g;
-    fe_store<P>(out + t, fe_load<P>(in + cls * (n4 >> log_g) + i));
+    // `in` is [chunk][class][piece]: entry i of class cls sits in chunk i / piece
+    const uint64_t j = i / piece, o = i - j * piece;
+    fe_store<P>(out + t, fe_load<P>(in + ((j << log_g) + cls) * piece + o));
 }
-template <class P> static int interleave_t(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G) {
+template <class P> static int interleave_t(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G, uint32_t chunks) {
     uint32_t lg = 0;
     while ((1u << lg) < G) ++lg;
-    hipLaunchKernelGGL(k_interleave<P>, dim3(nblocks(n4)), dim3(256), 0, c->stream, (const Fe<P>*)in, (Fe<P>*)out, (uint64_t)n4, lg);
+    const uint64_t m = n4 >> lg;
+    if (chunks == 0 || m % chunks) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "interleave: pieces must divide the class");
+    hipLaunchKernelGGL(k_interleave<P>, dim3(nblocks(n4)), dim3(256), 0, c->stream, (const Fe<P>*)in, (Fe<P>*)out, (uint64_t)n4, lg,
+                       m / chunks);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }
-int quotient_interleave(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G) { ZKT_DISPATCH(c, interleave_t, in, out, n4, G); }
+int quotient_interleave(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G, uint32_t chunks) {
+    ZKT_DISPATCH(c, interleave_t, in, out, n4, G, chunks);
+}
 
 // prove.rs:287-289: the three (n+2)-coefficient chunks of the quotient, each zero-padded to its buffer
 template <class P>

@@ -40,6 +40,8 @@ struct QuotientArgs {           // all vectors hold 4n coset evaluations
     // rotations in pi_tab are in class entries (4 pos / G).  G = 0 means the whole coset (G = 1, cls = 0, next_off = 4).
     uint32_t G, cls, next_off;
     const void *z1_next, *z2_next, *t_next, *h1_next;
+    // only the points [first, first + count) of the vectors (count = 0: all n4); out[i] is written for those i
+    uint64_t first, count;
 };
 constexpr int QUOTIENT_PI_DIRECT_MAX = 16;
 
@@ -81,8 +83,9 @@ int quotient_pointwise(zkt_ctx* c, const QuotientArgs& a);
 // in place: arkworks Montgomery form -> the quotient kernel's R' = 2^261 form times 32^k32 (k32 in {0, 1}).
 // quotient_pointwise expects q_l q_r q_o q_lookup q_table l1 with k32 = 0 and q_m with k32 = 1.
 int to_hat_form(zkt_ctx* c, void* v, size_t n, int k32);
-// class-major (rank r's n4 / G points at [r * n4 / G, ...)) -> natural order of the 4n coset: out[cls + G i] = in[cls * (n4 / G) + i]
-int quotient_interleave(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G);
+// class-major (rank r's n4 / G points at [r * n4 / G, ...)) -> natural order of the 4n coset: out[cls + G i] = in[cls * (n4 / G) + i].
+// chunks > 1: the exchange went out in pieces, `in` is [chunk][class][n4 / G / chunks]
+int quotient_interleave(zkt_ctx* c, const void* in, void* out, size_t n4, uint32_t G, uint32_t chunks = 1);
 int quotient_split_blind(zkt_ctx* c, const void* q, size_t n, const void* d_b0b1, void* q_lo, void* q_mid, void* q_hi,
                          uint32_t* d_status);                                                   // prove.rs:287-300
 // KZG opening witness: w = p / (X - z)  (kzg10::compute_witness_polynomial)

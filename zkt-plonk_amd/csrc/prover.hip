@@ -80,6 +80,8 @@ struct CircuitState {
     void* lk_keys = nullptr;     // insertion-order keys then sorted keys
     size_t lk_cap = 0;
     void* pinned = nullptr;
+    hipStream_t comm_stream = nullptr;   // sharded proof, asynchronous communicator: the quotient exchange's pieces travel here
+    hipEvent_t ev_piece[ZKT_QUOTIENT_CHUNKS] = {}, ev_gathered = nullptr;
     hipStream_t copy_stream = nullptr;   // host witness uploads travel beside the main stream's work (cold path)
     hipEvent_t ev_copy[4] = {};          // a, b, c uploaded; [3]: main stream reached the upload point
     void* pinned_pi = nullptr;      // host staging of pi_tab
@@ -706,10 +708,33 @@ struct Prover {
                 q.z2_next = S.G == 8 ? S.wnext[1] : q.z2;
                 q.t_next = S.G == 8 ? S.wnext[2] : q.t;
                 q.h1_next = S.G == 8 ? S.wnext[3] : q.h1;
-                q.out = (char*)S.qgather + (size_t)S.cls * S.m * 32;
-                if ((rc = quotient_pointwise(c, q))) return rc;
-                if ((rc = comm_all_gather_dev(c, q.out, S.qgather, S.m * 32))) return rc;
-                if ((rc = quotient_interleave(c, S.qgather, S.qev, 4 * n, (uint32_t)S.G))) return rc;
+                const size_t pieces = ZKT_QUOTIENT_CHUNKS;
+                if (comm_async_available(c) && S.comm_stream && S.m % pieces == 0 && S.m / pieces >= 1024) {
+                    // the exchange in pieces, stream-ordered, on a stream of its own: piece j's collective travels while
+                    // piece j + 1 is computed, and the host never waits (zkt_comm_vtable::all_gather_async).  The gathered
+                    // layout is [piece][class][m / pieces]; this rank's share of a piece is written where RCCL's in-place
+                    // form wants it (recv + rank * bytes).
+                    const size_t mp = S.m / pieces;
+                    for (size_t j = 0; j < pieces; ++j) {
+                        char* recv = (char*)S.qgather + j * (size_t)S.G * mp * 32;
+                        char* mine = recv + (size_t)S.cls * mp * 32;
+                        q.first = j * mp;
+                        q.count = mp;
+                        q.out = mine - q.first * 32;     // out[i] for i in the piece lands in `mine`
+                        if ((rc = quotient_pointwise(c, q))) return rc;
+                        ZKT_HIP(c, hipEventRecord(S.ev_piece[j], c->stream));
+                        ZKT_HIP(c, hipStreamWaitEvent(S.comm_stream, S.ev_piece[j], 0));
+                        if ((rc = comm_all_gather_async(c, mine, recv, mp * 32, S.comm_stream))) return rc;
+                    }
+                    ZKT_HIP(c, hipEventRecord(S.ev_gathered, S.comm_stream));
+                    ZKT_HIP(c, hipStreamWaitEvent(c->stream, S.ev_gathered, 0));
+                    if ((rc = quotient_interleave(c, S.qgather, S.qev, 4 * n, (uint32_t)S.G, (uint32_t)pieces))) return rc;
+                } else {
+                    q.out = (char*)S.qgather + (size_t)S.cls * S.m * 32;
+                    if ((rc = quotient_pointwise(c, q))) return rc;
+                    if ((rc = comm_all_gather_dev(c, q.out, S.qgather, S.m * 32))) return rc;
+                    if ((rc = quotient_interleave(c, S.qgather, S.qev, 4 * n, (uint32_t)S.G))) return rc;
+                }
             } else if ((rc = quotient_pointwise(c, q))) {
                 return rc;
             }
@@ -938,6 +963,12 @@ void circuit_release(zkt_ctx* c) {
         (void)hipStreamDestroy(S.copy_stream);
     }
     for (auto e : S.ev_copy) if (e) (void)hipEventDestroy(e);
+    if (S.comm_stream) {
+        (void)hipStreamSynchronize(S.comm_stream);
+        (void)hipStreamDestroy(S.comm_stream);
+    }
+    for (auto e : S.ev_piece) if (e) (void)hipEventDestroy(e);
+    if (S.ev_gathered) (void)hipEventDestroy(S.ev_gathered);
     c->circuit.reset();
 }
 
@@ -1008,6 +1039,11 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     if ((rc = alloc(&S.lk_keys, 2 * S.lk_cap))) return rc;
     ZKT_HIP(c, hipHostMalloc(&S.pinned, 64 * 32));
     ZKT_HIP(c, hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
+    if (S.G > 1) {
+        ZKT_HIP(c, hipStreamCreateWithFlags(&S.comm_stream, hipStreamNonBlocking));
+        for (auto& e : S.ev_piece) ZKT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ZKT_HIP(c, hipEventCreateWithFlags(&S.ev_gathered, hipEventDisableTiming));
+    }
     for (auto& e : S.ev_copy) ZKT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
@@ -1280,6 +1316,7 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
         rc = p.run(*in, proof);
         if (rc) {   // an early return may leave staged copies in flight
             (void)hipStreamSynchronize(c->circuit->copy_stream);
+            if (c->circuit->comm_stream) (void)hipStreamSynchronize(c->circuit->comm_stream);
             (void)hipStreamSynchronize(c->stream);
         }
     } else {
@@ -1287,6 +1324,7 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
         rc = p.run(*in, proof);
         if (rc) {
             (void)hipStreamSynchronize(c->circuit->copy_stream);
+            if (c->circuit->comm_stream) (void)hipStreamSynchronize(c->circuit->comm_stream);
             (void)hipStreamSynchronize(c->stream);
         }
     }

@@ -15,6 +15,7 @@ struct zkt_comm_rccl {
     hipStream_t own_stream = nullptr;   // host-buffer exchanges
     void* stage = nullptr;              // device staging: send slot + world receive slots
     size_t stage_bytes = 0;
+    bool dead = false;                  // a collective failed locally: the communicator was aborted, every later call fails
     std::string err;
 };
 
@@ -35,6 +36,18 @@ int fail(zkt_comm_rccl* c, int code, const char* what, const char* detail) {
         if (r_ != ncclSuccess) return fail((c), ZKT_ERR_COMM, #call, ncclGetErrorString(r_)); \
     } while (0)
 
+// A rank that fails inside an exchange must not leave its peers blocked in theirs: the communicator is aborted (the
+// peers' pending and later collectives then fail instead of hanging) and marked dead.  A communicator is used by ONE host
+// thread at a time (like the context it serves): the staging buffer and the error text are not guarded.
+int poison(zkt_comm_rccl* c, int rc) {
+    if (rc && c && c->comm && !c->dead) {
+        c->dead = true;
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+    }
+    return rc;
+}
+
 int ensure_stage(zkt_comm_rccl* c, size_t bytes) {
     if (c->stage_bytes >= bytes) return ZKT_OK;
     if (c->stage) CK_HIP(c, hipFree(c->stage));
@@ -45,9 +58,7 @@ int ensure_stage(zkt_comm_rccl* c, size_t bytes) {
     return ZKT_OK;
 }
 
-int all_gather(void* user, const void* send, void* recv, size_t bytes, int on_device, void* hip_stream) {
-    zkt_comm_rccl* c = static_cast<zkt_comm_rccl*>(user);
-    if (!c || !c->comm) return 1;
+int all_gather_impl(zkt_comm_rccl* c, const void* send, void* recv, size_t bytes, int on_device, void* hip_stream, bool wait) {
     if (bytes == 0) return 0;
     const size_t world = (size_t)c->world;
     CK_HIP(c, hipSetDevice(c->device));
@@ -63,7 +74,7 @@ int all_gather(void* user, const void* send, void* recv, size_t bytes, int on_de
             send = c->stage;
         }
         CK_NCCL(c, ncclAllGather(send, recv, bytes, ncclChar, c->comm, st));
-        CK_HIP(c, hipStreamSynchronize(st));   // the vtable's contract: complete when the callback returns
+        if (wait) CK_HIP(c, hipStreamSynchronize(st));   // all_gather's contract: complete when the callback returns
         return 0;
     }
     if (int rc = ensure_stage(c, bytes * (world + 1))) return rc;
@@ -74,6 +85,18 @@ int all_gather(void* user, const void* send, void* recv, size_t bytes, int on_de
     CK_HIP(c, hipMemcpyAsync(recv, dr, bytes * world, hipMemcpyDeviceToHost, c->own_stream));
     CK_HIP(c, hipStreamSynchronize(c->own_stream));
     return 0;
+}
+
+int all_gather(void* user, const void* send, void* recv, size_t bytes, int on_device, void* hip_stream) {
+    zkt_comm_rccl* c = static_cast<zkt_comm_rccl*>(user);
+    if (!c || !c->comm || c->dead) return 1;
+    return poison(c, all_gather_impl(c, send, recv, bytes, on_device, hip_stream, true));
+}
+// zkt_comm_vtable::all_gather_async: the same collective, enqueued on the caller's stream and left there
+int all_gather_async(void* user, const void* d_send, void* d_recv, size_t bytes, void* hip_stream) {
+    zkt_comm_rccl* c = static_cast<zkt_comm_rccl*>(user);
+    if (!c || !c->comm || c->dead) return 1;
+    return poison(c, all_gather_impl(c, d_send, d_recv, bytes, 1, hip_stream, false));
 }
 
 }  // namespace
@@ -122,6 +145,7 @@ int zkt_comm_rccl_vtable(zkt_comm_rccl* c, zkt_comm_vtable* out) {
     out->world = c->world;
     out->device_buffers = 1;
     out->all_gather = all_gather;
+    out->all_gather_async = all_gather_async;
     return ZKT_OK;
 }
 

@@ -195,9 +195,9 @@ class RcclLocalGroup:
     (the ranks share the GPU).  Not a substitute for a multi-GPU run: it checks the pointers, sizes, in-place rule and
     stream ordering the library hands a device transport, with a real RCCL call on them."""
 
-    def __init__(self, world: int, device: int = 0):
+    def __init__(self, world: int, device: int = 0, use_async: bool = True):
         import threading
-        self.world, self.device = world, device
+        self.world, self.device, self.use_async = world, device, use_async
         self.barrier = threading.Barrier(world)
         self.recv = [0] * world
         self.host_slots = [b""] * world
@@ -208,13 +208,21 @@ class RcclLocalGroup:
 
 class RcclLocalComm:
     def __init__(self, group: RcclLocalGroup, rank: int):
-        from ._lib import CommVtable, ALL_GATHER_CB, lib
+        from ._lib import CommVtable, ALL_GATHER_CB, ALL_GATHER_ASYNC_CB, lib
         self.group, self.rank, self.world = group, rank, group.world
         self.inner = RcclComm(RcclComm.unique_id(), 0, 1, group.device)
-        self.calls = self.device_calls = 0
+        self.calls = self.device_calls = self.async_calls = 0
         self._L = lib()
         self._cb = ALL_GATHER_CB(self._all_gather)
-        self.vt = CommVtable(None, rank, group.world, 1, self._cb)
+        # the stream-ordered entry (zkt_comm_vtable::all_gather_async): the library then sends the quotient exchange in
+        # pieces on its communication stream.  The rehearsal cannot be asynchronous (the ranks meet at a host barrier);
+        # what it checks is the pieces' pointers, sizes and order, and that the bytes still come out right
+        self._cb_async = ALL_GATHER_ASYNC_CB(self._all_gather_async) if group.use_async else ALL_GATHER_ASYNC_CB()
+        self.vt = CommVtable(None, rank, group.world, 1, self._cb, self._cb_async)
+
+    def _all_gather_async(self, user, send, recv, nbytes, stream):
+        self.async_calls += 1
+        return self._all_gather(user, send, recv, nbytes, 1, stream)
 
     def _all_gather(self, user, send, recv, nbytes, on_device, stream):
         try:
