@@ -371,6 +371,11 @@ typedef struct {
 size_t zkt_poseidon_gadget_vars_per_hash(const zkt_poseidon* params);
 int zkt_poseidon_gadget_witness_dev(zkt_ctx* ctx, const zkt_poseidon* params, const zkt_poseidon_gadget_args* args);
 int zkt_poseidon_gadget_check(zkt_ctx* ctx, const zkt_poseidon* params);
+/* Optional validation of ONE launch's arguments on the host (downloads the index vectors, synchronises): the traces must
+ * be pairwise disjoint and inside the map and no input index may be a variable the same launch writes -- the two rules
+ * zkt_poseidon_gadget_witness_dev cannot afford to check per proof and whose violation yields a stale or racy witness
+ * (the proof then fails to verify).  ZKT_ERR_INVALID_ARGUMENT names the rule.  Run it once per circuit layout. */
+int zkt_poseidon_gadget_validate(zkt_ctx* ctx, const zkt_poseidon* params, const zkt_poseidon_gadget_args* args);
 
 /* ---- Verifier (proof_system/proof.rs:285-503): zkt_verify_prepare = everything but the pairings,
  * ---- zkt_pairing_product_is_one = the pairings, zkt_verify = both ------------------------------------------------

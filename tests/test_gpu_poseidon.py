@@ -238,6 +238,22 @@ def test_gadget_witness_equals_the_composers_variables(cvname, w, kernel):
             ctx.free(d)
     with pytest.raises(L.ZktError):
         ctx.poseidon_gadget_witness_dev(h, 1, w, 1, 1, d_inputs=1)       # FullBuffer (spec.rs:253-257)
+    # zkt_poseidon_gadget_validate: the two structural rules a launch must obey, checked on request
+    per = ctx.poseidon_gadget_vars_per_hash(h)
+    nv = 3 * per + 8
+    d_map, d_b, d_i = ctx.alloc(nv * 32), ctx.alloc(8), ctx.alloc(8)
+    for bases, ins, ok in (([8, 8 + per], [0, 1], True), ([8, 8 + per - 1], [0, 1], False),      # overlapping traces
+                           ([8, 8 + per], [0, 8 + per + 3], False),                                # input made by this launch
+                           ([8, 8 + 2 * per + 1], [0, 1], False)):                                 # a trace leaves the map
+        ctx.upload(d_b, np.asarray(bases, dtype=np.uint32))
+        ctx.upload(d_i, np.asarray(ins, dtype=np.uint32))
+        if ok:
+            ctx.poseidon_gadget_witness_dev(h, 2, 1, d_map, nv, d_input_vars=d_i, d_trace_base=d_b, validate_only=True)
+        else:
+            with pytest.raises(L.ZktError):
+                ctx.poseidon_gadget_witness_dev(h, 2, 1, d_map, nv, d_input_vars=d_i, d_trace_base=d_b, validate_only=True)
+    for d in (d_map, d_b, d_i):
+        ctx.free(d)
     ctx.poseidon_free(h)
     ctx.close()
 

@@ -638,9 +638,11 @@ class Context:
 
     def poseidon_gadget_witness_dev(self, handle: int, batch: int, arity: int, d_variables: int, n_vars: int, d_inputs: int = 0,
                                     d_input_vars: int = 0, d_trace_base: int = 0, trace_base0: int = 0, d_out_hashes: int = 0,
-                                    kernel: int = 0):
+                                    kernel: int = 0, validate_only: bool = False):
         """zkt_poseidon_gadget_witness_dev: the variables PlonkSpecRef's gadget allocates for `batch` independent hashes,
-        written in allocation order into the variable map at d_variables (device pointers; enqueue only)."""
+        written in allocation order into the variable map at d_variables (device pointers; enqueue only).
+        validate_only: zkt_poseidon_gadget_validate on the same arguments instead (disjoint traces, no input made by the
+        same launch; synchronises, launches nothing)."""
         class Args(ctypes.Structure):
             _fields_ = [("batch", ctypes.c_size_t), ("arity", ctypes.c_int), ("d_inputs", ctypes.c_void_p),
                         ("d_input_vars", ctypes.c_void_p), ("d_variables", ctypes.c_void_p), ("n_vars", ctypes.c_size_t),
@@ -649,8 +651,9 @@ class Context:
         a = Args(batch, arity, d_inputs or None, d_input_vars or None, d_variables or None, n_vars, d_trace_base or None,
                  trace_base0, d_out_hashes or None, kernel)
         L = self._L
-        L.zkt_poseidon_gadget_witness_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Args)]
-        self.check(L.zkt_poseidon_gadget_witness_dev(self._h, ctypes.c_void_p(handle), ctypes.byref(a)))
+        fn = L.zkt_poseidon_gadget_validate if validate_only else L.zkt_poseidon_gadget_witness_dev
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Args)]
+        self.check(fn(self._h, ctypes.c_void_p(handle), ctypes.byref(a)))
 
     def poseidon_gadget_check(self, handle: int):
         """zkt_poseidon_gadget_check: synchronises; raises if a launch skipped a hash (index outside the variable map)."""

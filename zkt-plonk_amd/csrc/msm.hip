@@ -952,7 +952,10 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((rc = dev_alloc(c, (void**)&st->cnt2, ((size_t)st->l2_items << st->lcols) * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&st->pos2, ((size_t)st->l2_items << st->lcols) * 4))) return rc;
     {
-        const int lds = (int)(((3 * st->nb1 + 3) & ~3u) * 4 + MSM_L1_CAP * (st->packed ? 4 : 8));
+        // the attribute belongs to the kernel, not to this state: size it for the worst case of the instantiation (any
+        // number of level-1 bins), so that several states -- contexts in flight, thread-ranks with unequal SRS slices --
+        // cannot shrink each other's cap
+        const int lds = (int)(((3 * (uint32_t)MSM_MAX_NB1 + 3) & ~3u) * 4 + MSM_L1_CAP * (st->packed ? 4 : 8));
         const void* f = st->packed ? (const void*)msm_pick_bin_scatter<C, PairPacked>(st->dig)
                                    : (const void*)msm_pick_bin_scatter<C, PairWide>(st->dig);
         ZKT_HIP(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -10,6 +10,8 @@
 // Constants are the caller's (the reference generates them at run time, constants.rs:27, or parses the BN254 tables of
 // gadgets/src/poseidon).
 #include "ctx.hpp"
+#include <algorithm>
+#include <vector>
 
 #include <cstring>
 #include <vector>
@@ -606,6 +608,50 @@ int zkt_poseidon_gadget_witness_dev(zkt_ctx* c, const zkt_poseidon* h, const zkt
     (void)hipSetDevice(c->device);
     if (c->curve == ZKT_CURVE_BN254) return poseidon_gadget_enqueue_t<Bn254Fr>(c, h, *g);
     return poseidon_gadget_enqueue_t<Bls381Fr>(c, h, *g);
+}
+
+// Debug validation of one launch's structure (host side; synchronises): the traces [base, base + vars_per_hash) must be
+// pairwise disjoint and inside the map, and no input index may lie inside a trace of the SAME launch (the kernel's hashes
+// are independent: such an input would be read before, while or after it is written).  A caller that schedules its own
+// launches (the Python mirror does it in PoseidonGadget.levels) runs this once per circuit, not per proof.
+int zkt_poseidon_gadget_validate(zkt_ctx* c, const zkt_poseidon* h, const zkt_poseidon_gadget_args* g) {
+    if (!c || !h || !g) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (g->arity < 0 || g->arity > h->width - 1)
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon: arity <= width - 1 (spec.rs:253-257 FullBuffer)");
+    if (g->batch == 0) return ZKT_OK;
+    (void)hipSetDevice(c->device);
+    const size_t per = zkt_poseidon_gadget_vars_per_hash(h);
+    std::vector<uint64_t> base(g->batch);
+    if (g->d_trace_base) {
+        std::vector<uint32_t> b32(g->batch);
+        ZKT_HIP(c, hipMemcpyAsync(b32.data(), g->d_trace_base, g->batch * 4, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < g->batch; ++i) base[i] = b32[i];
+    } else {
+        for (size_t i = 0; i < g->batch; ++i) base[i] = g->trace_base0 + i * per;
+    }
+    std::vector<uint64_t> sorted(base);
+    std::sort(sorted.begin(), sorted.end());
+    for (size_t i = 0; i < sorted.size(); ++i) {
+        if (sorted[i] > g->n_vars || per > g->n_vars - sorted[i])
+            return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: a trace lies outside the variable map");
+        if (i && sorted[i] < sorted[i - 1] + per)
+            return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: two traces of one launch overlap");
+    }
+    if (g->arity && g->d_input_vars) {
+        std::vector<uint32_t> idx(g->batch * (size_t)g->arity);
+        ZKT_HIP(c, hipMemcpyAsync(idx.data(), g->d_input_vars, idx.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        for (uint32_t v : idx) {
+            if (v == 0xFFFFFFFFu) continue;   // Variable::Zero
+            if (v >= g->n_vars) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "poseidon gadget: an input index lies outside the variable map");
+            auto it = std::upper_bound(sorted.begin(), sorted.end(), (uint64_t)v);
+            if (it != sorted.begin() && (uint64_t)v < *(it - 1) + per)
+                return set_err(c, ZKT_ERR_INVALID_ARGUMENT,
+                               "poseidon gadget: an input is a variable the same launch writes (run it in a later launch)");
+        }
+    }
+    return ZKT_OK;
 }
 
 int zkt_poseidon_gadget_check(zkt_ctx* c, const zkt_poseidon* h) {

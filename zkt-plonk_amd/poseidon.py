@@ -99,9 +99,10 @@ class PoseidonGadget:
         self._staged = []
 
     def fill(self, d_variables: int, n_vars: int, check: bool = True) -> int:
-        """Enqueues the gadget kernel for every recorded call (one launch per arity) on the context's stream; the inputs
-        must already be in the map at d_variables and must not be outputs of these same calls.  Returns the number of
-        launches.  With check=True synchronises and raises when an index lay outside the map."""
+        """Enqueues the gadget kernel for every recorded call on the context's stream: ONE launch per dependency level
+        (`levels`: a call fed by another call's output runs in a later launch).  Inputs that no call makes must already be
+        in the map at d_variables.  Returns the number of launches.  With check=True synchronises and raises when an index
+        lay outside the map."""
         if not getattr(self, "_staged", None):
             self.stage()
         for arity, count, d_base, d_idx in self._staged:
