@@ -64,6 +64,10 @@ extern "C" {
     pub fn zkt_srs_load_file(ctx: *mut ZktCtx, ck_path: *const c_char, max_powers: usize) -> c_int;
     pub fn zkt_msm_g1(ctx: *mut ZktCtx, scalars: *const u64, len: usize, base_offset: usize, scalars_montgomery: c_int,
                       out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
+    pub fn zkt_commit_evals_dev(ctx: *mut ZktCtx, d_evals: *const c_void, blinders: *const u64, k: c_int, path: c_int,
+                                out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
+    pub fn zkt_ctx_set_lagrange(ctx: *mut ZktCtx, on: c_int) -> c_int;
+    pub fn zkt_lagrange_info(ctx: *mut ZktCtx, log_n: *mut c_int, bases: *mut usize) -> c_int;
     pub fn zkt_circuit_load(ctx: *mut ZktCtx, log_n: c_int, pk_polys: *const *const u64, pk_lens: *const usize) -> c_int;
     pub fn zkt_circuit_load_file(ctx: *mut ZktCtx, pk_path: *const c_char, log_n: c_int) -> c_int;
     pub fn zkt_circuit_setup(ctx: *mut ZktCtx, log_n: c_int, evals: *const *const u64, eval_lens: *const usize,

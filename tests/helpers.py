@@ -99,7 +99,7 @@ def run_sharded_ranks(z, cv, n, srs_arr, evals, vk, jobs, world, use_setup=True,
 
 
 def sharded_exchange_bytes(cv, n, world, n_proofs, same_table_proofs=0):
-    """Bytes ONE rank sends per the design (DESIGN.md section 5): per proof four all-gathers of the round's partial sums
+    """Bytes ONE rank sends per the design (DESIGN.md section 6): per proof four all-gathers of the round's partial sums
     (k = 6, 2, 3, 2 XYZZ points of 4 Fq each; the message has k entries whether or not the table commitment is cached)
     and ONE quotient exchange of exactly 4n * 32 / world bytes."""
     xyzz = 4 * cv.fq.limbs64 * 8
