@@ -378,6 +378,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     barrier()
     prof_acc = ctx.profile_get("msm_accumulate")
+    prof_acc_launches = ctx.profile_get("msm_accumulate#launches")[0]
     prof_idle = ctx.profile_get("host_wait")
     scope_names = ("msm_accumulate", "msm_main", "msm_lag_accumulate", "msm_lag_main", "msm_fold", "msm_tail", "ntt_%d" % log_n, "ntt_%d" % (log_n + 2), "quotient",
                    "round1", "round2", "round3", "round4", "round5")
@@ -539,9 +540,12 @@ def main():
         "kernel": "k_msm_accumulate", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_acc_s * 1e3, 4), "launches": acc_calls,
-        "launches_are": "the dense commitments only (coefficient-form MSMs of n + 2 .. n + 3 scalars); the Lagrange-basis "
-                        "commitments of t / h1 / h2 / z2 run the same kernel over a few thousand pairs and are listed under "
-                        "`commitments`",
+        "kernel_launches": prof_acc_launches,
+        "launches_are": "MSMs: the dense commitments only (coefficient-form MSMs of n + 2 .. n + 3 scalars), avg_launch_ms per "
+                        "MSM.  The three commitments of a round that exist together (a b c; q_lo q_mid q_hi) go out as ONE "
+                        "kernel launch with blockIdx.y = MSM, which rocprof lists as one dispatch of three times the work: "
+                        "`kernel_launches` dispatches covered `launches` MSMs.  The Lagrange-basis commitments of t / h1 / h2 / "
+                        "z2 run the same kernel over a few thousand pairs and are listed under `commitments`",
         "frac_of_mad_issue_ceiling": round(mads_per_add * mixed_adds / avg_acc_s / mad_ceiling, 4) if avg_acc_s > 0 else None,
         "frac_of_mad_issue_ceiling_at_residency": round(mads_per_add * mixed_adds / avg_acc_s / (mad_ceiling * MAD_CYCLES / MAD_CYCLES_RESIDENT), 4) if avg_acc_s > 0 else None,
         "valu_busy": valu_busy, "valu_busy_source": valu_src,

@@ -71,6 +71,8 @@ int zkt_ctx_synchronize(zkt_ctx* ctx);
  * commitments taken in the Lagrange basis (their pairs are few, they would dilute the dense kernel's average);
  * "host_wait": idle time of the context's stream across the prover's host round trips (from the moment the stream
  * drains while the host waits for a round's commitments or evaluations to the next launch; six per proof).
+ * A scope that covers a batch counts its units in `calls` (the three commitments of a round grouped and accumulated as one
+ * batch of launches: 3); "<name>#launches" returns the number of recorded scopes instead.
  * on = 0: off; 1: every scope; 2: only "msm_accumulate" and "host_wait" -- the level for timing the dominant kernel
  * and the stream's idle time live inside a throughput measurement (~18 event pairs per proof instead of ~80). */
 int zkt_profile_enable(zkt_ctx* ctx, int on);

@@ -139,6 +139,7 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(e1, stream);
     slot->pending.emplace_back(e0, e1);
     slot->calls += count;
+    ++slot->launches;
 }
 static void prof_resolve(zkt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
@@ -188,6 +189,7 @@ int zkt_ctx_create(int curve_id, int device_id, zkt_ctx** out) {
         return ZKT_ERR_NO_DEVICE;  // no CPU fallback by design
     if (hipSetDevice(device_id) != hipSuccess) return ZKT_ERR_NO_DEVICE;
     zkt_ctx* c = new zkt_ctx();
+    c->batch_off = exp_env("ZKT_MSM_NO_BATCH") != nullptr;
     c->curve = curve_id;
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -274,13 +276,19 @@ int zkt_profile_enable(zkt_ctx* c, int on) {
 int zkt_profile_get(zkt_ctx* c, const char* name, uint64_t* calls, double* total_ms) {
     if (!c || !name || !calls || !total_ms) return ZKT_ERR_INVALID_ARGUMENT;
     prof_resolve(c);
-    auto it = c->prof.find(name);
+    // "<scope>#launches": the number of scopes recorded instead of the units they stand for (a batched launch of three
+    // MSMs is one scope of three units)
+    std::string key(name);
+    const size_t hash = key.find("#launches");
+    const bool want_launches = hash != std::string::npos;
+    if (want_launches) key.resize(hash);
+    auto it = c->prof.find(key);
     if (it == c->prof.end()) {
         *calls = 0;
         *total_ms = 0.0;
         return ZKT_OK;
     }
-    *calls = it->second.calls;
+    *calls = want_launches ? it->second.launches : it->second.calls;
     *total_ms = it->second.total_ms;
     return ZKT_OK;
 }

@@ -43,7 +43,8 @@ struct zkt_ctx {
     struct ProfSlot {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
         double total_ms = 0.0;
-        uint64_t calls = 0;
+        uint64_t calls = 0;      // units (a batched launch of three MSMs counts three)
+        uint64_t launches = 0;   // scopes recorded (zkt_profile_get "<name>#launches")
     };
     std::map<std::string, ProfSlot> prof;
     std::vector<hipEvent_t> event_pool;
@@ -60,6 +61,7 @@ struct zkt_ctx {
     std::shared_ptr<zkt::MsmState> msm;
     uint64_t msm_epoch = 0;   // bumped by every MSM enqueue and SRS (re)load: work issued ahead of time is tied to it
     uint64_t srs_generation = 0;   // bumped by every SRS (re)load: cached commitments are tied to the key they were made under
+    bool batch_off = false;        // A/B builds: ZKT_MSM_NO_BATCH commits a round's polynomials one launch sequence each
     bool lagrange_off = false;     // zkt_ctx_set_lagrange(ctx, 0): evaluations are committed through their coefficients
     std::shared_ptr<zkt::CircuitState> circuit;
     std::vector<void*> owned;  // every hipMalloc made on behalf of this ctx

@@ -287,10 +287,14 @@ ZKT_D uint32_t block_excl_scan_256(uint32_t mine, uint32_t* wsum) {
 }
 
 template <class C, int DIG>
-__global__ __launch_bounds__(1024) void k_msm_bin_count(const Fe<typename C::Fr>* scalars, size_t n, int mont,
+__global__ __launch_bounds__(1024) void k_msm_bin_count(MsmBatch bt, int mont,
                                                         MsmWindows win, uint32_t per_block, uint32_t nb1, uint32_t lb,
                                                         uint32_t* counts) {
     using R = typename C::Fr;
+    const uint32_t y = blockIdx.y;
+    const Fe<R>* scalars = (const Fe<R>*)bt.scalars[y];
+    const size_t n = bt.n[y];
+    counts += y * bt.s_bin_offs;
     extern __shared__ uint32_t lds[];
     uint32_t* hist = lds;
     for (uint32_t b = threadIdx.x; b < nb1; b += 1024) hist[b] = 0;
@@ -322,8 +326,10 @@ __global__ __launch_bounds__(1024) void k_msm_bin_count(const Fe<typename C::Fr>
 // exclusive scan of the level-1 counts in two small launches: 4096-element tiles scanned in place, then the
 // tile totals (aux).  Readers add the two parts themselves: off(i) = counts[i] + aux[i >> 12].
 constexpr int MSM_SCAN_TILE = 4096;
-__global__ __launch_bounds__(1024) void k_msm_scan_tiles(uint32_t* counts, uint32_t total, uint32_t* aux) {
+__global__ __launch_bounds__(1024) void k_msm_scan_tiles(uint32_t* counts, uint32_t total, uint32_t* aux, MsmBatch bt) {
     __shared__ uint32_t wsum[16];
+    counts += blockIdx.y * bt.s_bin_offs;
+    aux += blockIdx.y * bt.s_bin_aux;
     const uint32_t i0 = blockIdx.x * MSM_SCAN_TILE + threadIdx.x * 4;
     uint32_t v[4];
 #pragma unroll
@@ -346,9 +352,16 @@ ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, 
 // crowded-bucket counter of this MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
 __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uint32_t* aux, uint32_t nt, uint32_t nblk,
                                                        uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start,
-                                                       uint2* tile_desc, uint32_t* heavy_count, uint32_t acc_threads,
-                                                       uint32_t B, uint32_t* params) {
+                                                       uint2* tile_desc, uint32_t acc_threads, uint32_t B, MsmBatch bt) {
     __shared__ uint32_t wsum[16];
+    const uint32_t y = blockIdx.y;
+    offs += y * bt.s_bin_offs;
+    aux += y * bt.s_bin_aux;
+    bin_start += y * bt.s_bin;
+    tile_start += y * bt.s_bin;
+    tile_desc += y * bt.s_tile_desc;
+    uint32_t* heavy_count = bt.heavy[y];
+    uint32_t* params = bt.params[y];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nt; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -398,11 +411,17 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uin
 // Every workgroup orders its pairs by bin in LDS (positions from LDS atomics on the bin cursors), then one wavefront
 // per bin copies the bin's run to its place in `pairs`: 64 consecutive entries per instruction.
 template <class C, class PF, int DIG>
-__global__ __launch_bounds__(1024) void k_msm_bin_scatter(const Fe<typename C::Fr>* scalars, size_t n, int mont,
+__global__ __launch_bounds__(1024) void k_msm_bin_scatter(MsmBatch bt, int mont,
                                                           MsmWindows win, uint32_t per_block, size_t count,
-                                                          size_t base_off, uint32_t nb1, uint32_t lb, const uint32_t* offs,
+                                                          uint32_t nb1, uint32_t lb, const uint32_t* offs,
                                                           const uint32_t* aux, typename PF::type* pairs) {
     using R = typename C::Fr;
+    const uint32_t y = blockIdx.y;
+    const Fe<R>* scalars = (const Fe<R>*)bt.scalars[y];
+    const size_t n = bt.n[y], base_off = bt.base_off[y];
+    offs += y * bt.s_bin_offs;
+    aux += y * bt.s_bin_aux;
+    pairs = reinterpret_cast<typename PF::type*>(reinterpret_cast<char*>(pairs) + y * bt.s_pairs_bytes);
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wsum[16];
     uint32_t* cursor = lds;
@@ -474,8 +493,16 @@ ZKT_D L2Item msm_l2_item(uint32_t item, uint32_t nb1, const uint32_t* tile_start
 // lb = 10: the digit widths c = 19, 20 that pay at n >= 2^22, where W n additions outweigh 2^(c-1) buckets to reduce).
 template <class PF, int LC>
 __global__ __launch_bounds__(256) void k_msm_l2_count(const typename PF::type* pairs, uint32_t nb1, uint32_t lb,
-                                                      const uint32_t* tile_start, const uint2* tile_desc, uint32_t* cnt2) {
+                                                      const uint32_t* tile_start, const uint2* tile_desc, uint32_t* cnt2,
+                                                      MsmBatch bt) {
     constexpr uint32_t COLS = 1u << LC;
+    {
+        const uint32_t y = blockIdx.y;
+        pairs = reinterpret_cast<const typename PF::type*>(reinterpret_cast<const char*>(pairs) + y * bt.s_pairs_bytes);
+        tile_start += y * bt.s_bin;
+        tile_desc += y * bt.s_tile_desc;
+        cnt2 += y * bt.s_cnt;
+    }
     __shared__ uint32_t hist[COLS];
     const L2Item it = msm_l2_item(blockIdx.x, nb1, tile_start, tile_desc);
     if (!it.valid) return;
@@ -506,10 +533,17 @@ __global__ __launch_bounds__(256) void k_msm_l2_count(const typename PF::type* p
 // consecutive columns t K .. t K + K - 1.
 template <int LC>
 __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint32_t* pos2, const uint32_t* bin_start,
-                                                     const uint32_t* tile_start, uint32_t* offsets, uint32_t B, uint32_t lb,
-                                                     const uint32_t* params, uint32_t* chunk_bucket) {
+                                                     const uint32_t* tile_start, uint32_t B, uint32_t lb,
+                                                     uint32_t* chunk_bucket, MsmBatch bt) {
     constexpr uint32_t COLS = 1u << LC, K = COLS / 256u;
-    const uint32_t chunk = params[0];
+    const uint32_t y = blockIdx.y;
+    cnt2 += y * bt.s_cnt;
+    pos2 += y * bt.s_cnt;
+    bin_start += y * bt.s_bin;
+    tile_start += y * bt.s_bin;
+    chunk_bucket += y * bt.s_chunk;
+    uint32_t* offsets = bt.offsets[y];
+    const uint32_t chunk = bt.params[y][0];
     const uint32_t b = blockIdx.x;
     const uint32_t t0 = tile_start[b], t1 = tile_start[b + 1];
     uint32_t run[K];
@@ -575,8 +609,17 @@ template <class PF, int LC>
 __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typename PF::type* pairs, uint32_t nb1, uint32_t lb,
                                                                     const uint32_t* tile_start, const uint2* tile_desc,
                                                                     const uint32_t* cnt2, const uint32_t* pos2,
-                                                                    uint32_t* vals) {
+                                                                    uint32_t* vals, MsmBatch bt) {
     constexpr uint32_t COLS = 1u << LC;
+    {
+        const uint32_t y = blockIdx.y;
+        pairs = reinterpret_cast<const typename PF::type*>(reinterpret_cast<const char*>(pairs) + y * bt.s_pairs_bytes);
+        tile_start += y * bt.s_bin;
+        tile_desc += y * bt.s_tile_desc;
+        cnt2 += y * bt.s_cnt;
+        pos2 += y * bt.s_cnt;
+        vals += y * bt.s_vals;
+    }
     typedef typename std::conditional<(LC <= 8), uint8_t, uint16_t>::type key_t;
     __shared__ uint32_t cursor[COLS], delta[COLS], wsum[16];
     __shared__ uint32_t sval[MSM_L2_TILE];
@@ -627,12 +670,15 @@ __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typena
 // packed words in R' Montgomery form, the pieces are the raw limbs (XyzzRaw).
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, const uint32_t* params,
-                                                        const uint32_t* offsets, const uint32_t* chunk_bucket,
-                                                        const Affine<typename C::Fq>* table,
-                                                        XyzzRaw<typename C::Fq>* pieces) {
+__global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, const uint32_t* chunk_bucket,
+                                                        const Affine<typename C::Fq>* table, MsmBatch bt) {
     using Q = typename C::Fq;
-    const uint32_t chunk = params[0];
+    const uint32_t y = blockIdx.y;
+    vals += y * bt.s_vals;
+    chunk_bucket += y * bt.s_chunk;
+    const uint32_t* offsets = bt.offsets[y];
+    XyzzRaw<Q>* pieces = (XyzzRaw<Q>*)bt.pieces[y];
+    const uint32_t chunk = bt.params[y][0];
     const uint32_t base = offsets[1], m = offsets[B + 1];   // first / one past the last pair with a non-zero bucket
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p0 = (uint64_t)base + (uint64_t)t * chunk;
@@ -679,11 +725,13 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_bucket_sum(const uint32_t* offsets, uint32_t B, const uint32_t* params,
-                                                        const XyzzRaw<typename C::Fq>* pieces,
-                                                        Xyzz<typename C::Fq>* buckets, uint32_t* heavy) {
+__global__ __launch_bounds__(256) void k_msm_bucket_sum(uint32_t B, MsmTailBatch tb) {
     using Q = typename C::Fq;
-    const uint32_t chunk = params[0];
+    const uint32_t* offsets = tb.offsets[blockIdx.y];
+    const XyzzRaw<Q>* pieces = (const XyzzRaw<Q>*)tb.pieces[blockIdx.y];
+    Xyzz<Q>* buckets = (Xyzz<Q>*)tb.buckets[blockIdx.y];
+    uint32_t* heavy = tb.heavy[blockIdx.y];
+    const uint32_t chunk = tb.params[blockIdx.y][0];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;  // 0..B ; bucket 0 is the identity
     if (b > B) return;
     XyzzX<Q> acc = xx_identity<Q>();
@@ -739,11 +787,13 @@ ZKT_D XyzzX<Q> block_sum_256(XyzzX<Q> acc, Xyzz<Q>* wsum) {
 
 // crowded buckets (skewed digit distributions): one block folds all pieces of one bucket
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_heavy(const uint32_t* offsets, const uint32_t* params,
-                                                   const XyzzRaw<typename C::Fq>* pieces,
-                                                   Xyzz<typename C::Fq>* buckets, const uint32_t* heavy) {
+__global__ __launch_bounds__(256) void k_msm_heavy(MsmTailBatch tb) {
     using Q = typename C::Fq;
-    const uint32_t chunk = params[0];
+    const uint32_t* offsets = tb.offsets[blockIdx.y];
+    const XyzzRaw<Q>* pieces = (const XyzzRaw<Q>*)tb.pieces[blockIdx.y];
+    Xyzz<Q>* buckets = (Xyzz<Q>*)tb.buckets[blockIdx.y];
+    const uint32_t* heavy = tb.heavy[blockIdx.y];
+    const uint32_t chunk = tb.params[blockIdx.y][0];
     __shared__ Xyzz<Q> wsum[4];
     const uint32_t nheavy = heavy[0];
     const uint32_t base = offsets[1];
@@ -780,9 +830,10 @@ ZKT_D XyzzX<Q> wave_sum(XyzzX<Q> acc) {   // valid in lane 0
 
 // wavefront w < NI: R_w = sum_j bucket[w NJ + j];  NI <= w < NI + NJ: C_(w - NI) = sum_i bucket[i NJ + (w - NI)]
 template <class C>
-__global__ __launch_bounds__(256) void k_msm_rowcol(const Xyzz<typename C::Fq>* buckets, uint32_t q1, uint32_t q2,
-                                                    Xyzz<typename C::Fq>* rc) {
+__global__ __launch_bounds__(256) void k_msm_rowcol(uint32_t q1, uint32_t q2, MsmTailBatch tb) {
     using Q = typename C::Fq;
+    const Xyzz<Q>* buckets = (const Xyzz<Q>*)tb.buckets[blockIdx.y];
+    Xyzz<Q>* rc = (Xyzz<Q>*)tb.rowcol[blockIdx.y];
     const uint32_t NI = 1u << q1, NJ = 1u << q2;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -803,10 +854,11 @@ __global__ __launch_bounds__(256) void k_msm_rowcol(const Xyzz<typename C::Fq>* 
 // alone.  Written in arkworks' R form straight into pinned host memory: the host applies the weights 2^y
 // (hostec.hpp weighted_row_sum) -- the remaining ~35 dependent curve operations cost a wavefront 0.6 ms and the host 15 us.
 template <class C>
-__global__ __launch_bounds__(64) void k_msm_weighted_rows(const Xyzz<typename C::Fq>* rc, uint32_t q1, uint32_t q2,
-                                                          const Xyzz<typename C::Fq>* top_bucket,
-                                                          Xyzz<typename C::Fq>* partials) {
+__global__ __launch_bounds__(64) void k_msm_weighted_rows(uint32_t q1, uint32_t q2, uint32_t B, MsmTailBatch tb) {
     using Q = typename C::Fq;
+    const Xyzz<Q>* rc = (const Xyzz<Q>*)tb.rowcol[blockIdx.y];
+    const Xyzz<Q>* top_bucket = (const Xyzz<Q>*)tb.buckets[blockIdx.y] + B;
+    Xyzz<Q>* partials = (Xyzz<Q>*)tb.partials[blockIdx.y];
     const uint32_t NI = 1u << q1, NJ = 1u << q2;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t y = blockIdx.x;
@@ -921,8 +973,14 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     int rc;
     if ((rc = dev_alloc(c, &st->table, (size_t)st->W * count * sizeof(Affine<Q>)))) return rc;
     size_t m = (size_t)st->W * count;
-    if ((rc = dev_alloc(c, (void**)&st->vals2, m * 4))) return rc;
-    if ((rc = dev_alloc(c, &st->pairs, m * 8))) return rc;
+    // the main-stream work buffers exist MSM_BATCH times (a round's commitments are grouped and accumulated as one batch:
+    // msm_enqueue_batch); strides between the copies in st->strides
+    constexpr size_t NB = MSM_BATCH;
+    auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };   // keep every copy 256-byte aligned
+    st->strides.s_vals = up(m);
+    st->strides.s_pairs_bytes = up(m) * 8;
+    if ((rc = dev_alloc(c, (void**)&st->vals2, NB * st->strides.s_vals * 4))) return rc;
+    if ((rc = dev_alloc(c, &st->pairs, NB * st->strides.s_pairs_bytes))) return rc;
     {   // pair format: one 32-bit word when low key bits + table index + sign fit (see PairPacked)
         int idx_bits = 1;
         while ((m - 1) >> idx_bits) ++idx_bits;
@@ -943,14 +1001,19 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     st->l1_scalars = (l1_cap / (uint32_t)st->W) & ~63u;
     if (st->l1_scalars > 1024u) st->l1_scalars = 1024u;
     const size_t max_blk = (count + st->l1_scalars - 1) / st->l1_scalars;
-    if ((rc = dev_alloc(c, (void**)&st->bin_offs, ((size_t)st->nb1 * max_blk + 1) * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->bin_aux, ((size_t)st->nb1 * max_blk / MSM_SCAN_TILE + 4) * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->bin_start, ((size_t)st->nb1 + 1) * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->tile_start, ((size_t)st->nb1 + 1) * 4))) return rc;
+    st->strides.s_bin_offs = up((size_t)st->nb1 * max_blk + 1);
+    st->strides.s_bin_aux = up((size_t)st->nb1 * max_blk / MSM_SCAN_TILE + 4);
+    st->strides.s_bin = up((size_t)st->nb1 + 1);
     st->l2_items = (uint32_t)(m / MSM_L2_TILE + st->nb1);
-    if ((rc = dev_alloc(c, &st->tile_desc, (size_t)st->l2_items * 8))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->cnt2, ((size_t)st->l2_items << st->lcols) * 4))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->pos2, ((size_t)st->l2_items << st->lcols) * 4))) return rc;
+    st->strides.s_tile_desc = up(st->l2_items);
+    st->strides.s_cnt = up((size_t)st->l2_items << st->lcols);
+    if ((rc = dev_alloc(c, (void**)&st->bin_offs, NB * st->strides.s_bin_offs * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->bin_aux, NB * st->strides.s_bin_aux * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->bin_start, NB * st->strides.s_bin * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->tile_start, NB * st->strides.s_bin * 4))) return rc;
+    if ((rc = dev_alloc(c, &st->tile_desc, NB * st->strides.s_tile_desc * 8))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->cnt2, NB * st->strides.s_cnt * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&st->pos2, NB * st->strides.s_cnt * 4))) return rc;
     {
         // the attribute belongs to the kernel, not to this state: size it for the worst case of the instantiation (any
         // number of level-1 bins), so that several states -- contexts in flight, thread-ranks with unequal SRS slices --
@@ -996,7 +1059,8 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     size_t max_chunks = std::min(m, st->acc_threads) + 1;
     for (int i = 0; i < MsmState::SLOTS; ++i)
         if ((rc = dev_alloc(c, &st->pieces[i], (max_chunks + st->B + 2) * sizeof(XyzzRaw<Q>)))) return rc;
-    if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, (max_chunks + 2) * 4))) return rc;
+    st->strides.s_chunk = up(max_chunks + 2);
+    if ((rc = dev_alloc(c, (void**)&st->chunk_bucket, NB * st->strides.s_chunk * 4))) return rc;
     ZKT_HIP(c, hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         if ((rc = dev_alloc(c, &st->buckets[i], ((size_t)st->B + 1) * sizeof(Xyzz<Q>)))) return rc;
@@ -1009,6 +1073,8 @@ static int msm_setup(zkt_ctx* c, size_t count) {
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
         ZKT_HIP(c, hipEventCreateWithFlags(&st->ev_done[i], hipEventDisableTiming));
     }
+    st->defer_tails = count <= MSM_DEFER_MAX;
+    if (const char* e = exp_env("ZKT_MSM_DEFER")) st->defer_tails = atoi(e) != 0;
     c->msm = st;
     ++c->msm_epoch;
     ++c->srs_generation;
@@ -1122,109 +1188,169 @@ static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t
     return srs_finish<C>(c);
 }
 
-// enqueue the whole MSM; its partial sums land in st.host_result[slot] (pinned), see msm_host_finish
+// The bucket fold and reduction of every slot in st.tail_wait as ONE sequence of four launches (blockIdx.y = slot), behind
+// the accumulation of the last of them.
 template <class C>
-static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0, int tbl = 0) {
-    using Q = typename C::Fq;
-    using R = typename C::Fr;
+static int msm_launch_tails(zkt_ctx* c) {
     MsmState& st = *c->msm;
+    const int k = st.n_tail_wait;
+    if (k == 0) return ZKT_OK;
+    st.n_tail_wait = 0;
+    MsmTailBatch tb{};
+    for (int j = 0; j < MSM_TAIL_BATCH; ++j) {
+        const int slot = st.tail_wait[j < k ? j : 0];
+        tb.offsets[j] = st.offsets[slot];
+        tb.params[j] = st.params[slot];
+        tb.pieces[j] = st.pieces[slot];
+        tb.buckets[j] = st.buckets[slot];
+        tb.heavy[j] = st.heavy[slot];
+        tb.rowcol[j] = st.rowcol[slot];
+        tb.partials[j] = st.host_result_dev[slot];
+    }
+    const unsigned ky = (unsigned)k;
+    ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[st.tail_wait[k - 1]], 0));
+    {
+    ProfScope prof_fold(c, "msm_fold", st.side, (uint64_t)k);
+    hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
+    ZKT_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS, ky), dim3(256), 0, st.side, tb);
+    ZKT_HIP(c, hipGetLastError());
+    }
+    {
+    ProfScope prof_tail(c, "msm_tail", st.side, (uint64_t)k);
+    const uint32_t q = (uint32_t)(st.c - 1), q2 = q / 2, q1 = q - q2;   // 2^q buckets below B = 2^q1 rows x 2^q2 columns
+    const uint32_t sums = (1u << q1) + (1u << q2);
+    hipLaunchKernelGGL(k_msm_rowcol<C>, dim3((sums + 3) / 4, ky), dim3(256), 0, st.side, q1, q2, tb);
+    ZKT_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(k_msm_weighted_rows<C>, dim3(q + 1, ky), dim3(64), 0, st.side, q1, q2, st.B, tb);
+    ZKT_HIP(c, hipGetLastError());
+    }
+    // the ny + 1 row sums are written straight into pinned host memory (16 posted writes of 128 B; a copy engine took
+    // ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
+    for (int j = 0; j < k; ++j) ZKT_HIP(c, hipEventRecord(st.ev_done[st.tail_wait[j]], st.side));
+    return ZKT_OK;
+}
+
+// Enqueues k <= MSM_BATCH MSMs over the same table as ONE batch: every grouping kernel and the accumulation go out once,
+// with blockIdx.y = MSM (the commitments of a prover round are independent: prove.rs:133-135,306-308 -- three launches of a
+// latency-bound kernel cost three ramps and tails, one launch of three times the blocks costs one).  The partial sums of MSM j
+// land in st.host_result[slots[j]] (pinned), see msm_host_finish.  k = 1 is the single MSM.
+template <class C>
+static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, const size_t* base_offs, int mont,
+                             const int* slots, int tbl = 0) {
+    using Q = typename C::Fq;
+    MsmState& st = *c->msm;
+    if (k < 1 || k > MSM_BATCH) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm batch size");
+    ++c->msm_epoch;   // slot buffers change hands: anything issued ahead of time that relied on them is stale
+    for (int j = 0; j < k; ++j)    // a slot that is enqueued again before its deferred tail went out: issue the tails now
+        for (int w = 0; w < st.n_tail_wait; ++w)
+            if (st.tail_wait[w] == slots[j])
+                if (int rc0 = msm_launch_tails<C>(c)) return rc0;
+    if (st.n_tail_wait + k > MSM_TAIL_BATCH)
+        if (int rc0 = msm_launch_tails<C>(c)) return rc0;
     // tbl = 1: the Lagrange-prefix table of lagrange.hip (count2 bases) instead of the key's powers
     const void* table = tbl ? st.table2 : st.table;
     const size_t tcount = tbl ? st.count2 : st.count;
-    ++c->msm_epoch;   // slot buffers change hands: anything issued ahead of time that relied on them is stale
-    // the slot's buffers may still be read by the previous MSM that used this slot (side stream)
-    if (st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
+    MsmBatch bt = st.strides;
+    size_t n_max = 0;
+    for (int j = 0; j < MSM_BATCH; ++j) {
+        const int jj = j < k ? j : 0;
+        const int slot = slots[jj];
+        // the slot's buffers may still be read by the previous MSM that used this slot (side stream)
+        if (j < k && st.pending[slot]) ZKT_HIP(c, hipStreamWaitEvent(c->stream, st.ev_done[slot], 0));
+        bt.scalars[j] = d_scalars[jj];
+        bt.n[j] = ns[jj];
+        bt.base_off[j] = base_offs[jj];
+        bt.heavy[j] = st.heavy[slot];
+        bt.params[j] = st.params[slot];
+        bt.offsets[j] = st.offsets[slot];
+        bt.pieces[j] = st.pieces[slot];
+        if (j < k) n_max = std::max(n_max, ns[jj]);
+    }
+    const size_t n = n_max;
     const uint32_t m = (uint32_t)((size_t)st.W * n);
-    // one chunk per thread, two wave-fronts of threads (see msm_setup): equal chunks keep the lanes balanced whatever the
-    // digit distribution, the second wave-front absorbs the workgroups the side stream's kernels delayed
+    const unsigned ky = (unsigned)k;
     // (the chunk itself is computed on the device from the pairs that really exist: k_msm_scan_aux -> params[slot])
     {
-    ProfScope prof_all(c, tbl ? "msm_lag_main" : "msm_main");   // Lagrange-basis commitments are timed apart: their pairs are few
+    ProfScope prof_all(c, tbl ? "msm_lag_main" : "msm_main", nullptr, (uint64_t)k);   // Lagrange-basis commitments are timed apart
     {
         const uint32_t S = st.l1_scalars;
         const unsigned nblk = (unsigned)((n + S - 1) / S);
         const uint32_t total = st.nb1 * nblk, ntiles = (total + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE;
         {
             auto kc = msm_pick_bin_count<C>(st.dig);
-            hipLaunchKernelGGL(kc, dim3(nblk), dim3(1024), (size_t)st.nb1 * 4, c->stream, (const Fe<R>*)d_scalars, n, mont,
-                               st.win, S, st.nb1, st.lb, st.bin_offs);
+            hipLaunchKernelGGL(kc, dim3(nblk, ky), dim3(1024), (size_t)st.nb1 * 4, c->stream, bt, mont, st.win, S, st.nb1, st.lb,
+                               st.bin_offs);
         }
-        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux);
-        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
-                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, st.heavy[slot], (uint32_t)st.acc_threads, st.B,
-                           st.params[slot]);
+        hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles, ky), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux, bt);
+        hipLaunchKernelGGL(k_msm_scan_aux, dim3(1, ky), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
+                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, (uint32_t)st.acc_threads, st.B, bt);
         ZKT_HIP(c, hipGetLastError());
         const size_t lds_scatter = (size_t)((3 * st.nb1 + 3) & ~3u) * 4 + (size_t)MSM_L1_CAP * (st.packed ? 4 : 8);
         const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
         if (st.packed) {
             auto ks = msm_pick_bin_scatter<C, PairPacked>(st.dig);
-            hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
-                               tcount, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
+            hipLaunchKernelGGL(ks, dim3(nblk, ky), dim3(1024), lds_scatter, c->stream, bt, mont, st.win, S,
+                               tcount, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
-            hipLaunchKernelGGL((k_msm_l2_count<PairPacked, 8>), dim3(items), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
-                               st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
+            hipLaunchKernelGGL((k_msm_l2_count<PairPacked, 8>), dim3(items, ky), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
+                               st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, bt);
         } else {
             auto ks = msm_pick_bin_scatter<C, PairWide>(st.dig);
-            hipLaunchKernelGGL(ks, dim3(nblk), dim3(1024), lds_scatter, c->stream, (const Fe<R>*)d_scalars, n, mont, st.win, S,
-                               tcount, base_off, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+            hipLaunchKernelGGL(ks, dim3(nblk, ky), dim3(1024), lds_scatter, c->stream, bt, mont, st.win, S,
+                               tcount, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
             auto kc2 = st.lcols == 8 ? k_msm_l2_count<PairWide, 8> : k_msm_l2_count<PairWide, 10>;
-            hipLaunchKernelGGL(kc2, dim3(items), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
-                               st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2);
+            hipLaunchKernelGGL(kc2, dim3(items, ky), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+                               st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, bt);
         }
         {
             auto ksc = st.lcols == 8 ? k_msm_l2_scan<8> : k_msm_l2_scan<10>;
-            hipLaunchKernelGGL(ksc, dim3(st.nb1), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
-                               st.tile_start, st.offsets[slot], st.B, st.lb, st.params[slot], st.chunk_bucket);
+            hipLaunchKernelGGL(ksc, dim3(st.nb1, ky), dim3(256), 0, c->stream, st.cnt2, st.pos2, st.bin_start,
+                               st.tile_start, st.B, st.lb, st.chunk_bucket, bt);
         }
         if (st.packed) {
-            hipLaunchKernelGGL((k_msm_l2_scatter<PairPacked, 8>), dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint32_t*)st.pairs,
-                               st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2);
+            hipLaunchKernelGGL((k_msm_l2_scatter<PairPacked, 8>), dim3(items, ky), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint32_t*)st.pairs,
+                               st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2, bt);
         } else {
             auto kss = st.lcols == 8 ? k_msm_l2_scatter<PairWide, 8> : k_msm_l2_scatter<PairWide, 10>;
-            hipLaunchKernelGGL(kss, dim3(items), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint2*)st.pairs, st.nb1,
-                               st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2);
+            hipLaunchKernelGGL(kss, dim3(items, ky), dim3(MSM_L2S_THREADS), 0, c->stream, (const uint2*)st.pairs, st.nb1,
+                               st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, st.pos2, st.vals2, bt);
         }
         ZKT_HIP(c, hipGetLastError());
     }
-    {
-        ProfScope prof_acc(c, tbl ? "msm_lag_accumulate" : "msm_accumulate");
-        // as many threads as the MSM can have chunks (threads past the last chunk leave at once)
-        const uint32_t max_chunks = (uint32_t)std::min((size_t)m, st.acc_threads);
-        hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256), dim3(256), st.acc_lds, c->stream, st.vals2,
-                           st.B, st.params[slot], st.offsets[slot], st.chunk_bucket, (const Affine<Q>*)table, (XyzzRaw<Q>*)st.pieces[slot]);
-        ZKT_HIP(c, hipGetLastError());
+    // Accumulation and tail, one MSM after the other even when the grouping was batched: the bucket reduction of MSM j
+    // (side stream) then runs beside the accumulation of MSM j + 1, which absorbs it (two wave-fronts of chunks); issued
+    // together behind the batch the three tails ran beside the transforms that follow a round and slowed them by 8-10 %.
+    for (int j = 0; j < k; ++j) {
+        MsmBatch one = bt;
+        one.offsets[0] = bt.offsets[j];
+        one.pieces[0] = bt.pieces[j];
+        one.params[0] = bt.params[j];
+        {
+            ProfScope prof_acc(c, tbl ? "msm_lag_accumulate" : "msm_accumulate");
+            // as many threads as an MSM can have chunks (threads past the last chunk leave at once)
+            const uint32_t max_chunks = (uint32_t)std::min((size_t)st.W * ns[j], st.acc_threads);
+            hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256, 1), dim3(256), st.acc_lds, c->stream,
+                               st.vals2 + (size_t)j * st.strides.s_vals, st.B, st.chunk_bucket + (size_t)j * st.strides.s_chunk,
+                               (const Affine<Q>*)table, one);
+            ZKT_HIP(c, hipGetLastError());
+        }
+        // ---- tail on the side stream: the bucket fold (latency bound: one wave per SIMD, a few dependent additions) and
+        // the bucket reduction overlap whatever the main stream does next; everything they read is the slot's own ----
+        ZKT_HIP(c, hipEventRecord(st.ev_main[slots[j]], c->stream));
+        st.tail_wait[st.n_tail_wait++] = slots[j];
+        st.pending[slots[j]] = true;
+        if (st.defer_tails && st.n_tail_wait < MSM_TAIL_BATCH) continue;   // msm_flush_tails, once per round
+        if (int rc = msm_launch_tails<C>(c)) return rc;
     }
-    }
-    // ---- tail on the side stream: the bucket fold (latency bound: one wave per SIMD, a few dependent additions) and the
-    // bucket reduction overlap whatever the main stream does next; everything they read is the slot's own ----
-    ZKT_HIP(c, hipEventRecord(st.ev_main[slot], c->stream));
-    ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[slot], 0));
-    {
-    ProfScope prof_fold(c, "msm_fold", st.side);
-    hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256), dim3(256), 0, st.side, st.offsets[slot], st.B,
-                       st.params[slot], (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
-    ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS), dim3(256), 0, st.side, st.offsets[slot], st.params[slot],
-                       (const XyzzRaw<Q>*)st.pieces[slot], (Xyzz<Q>*)st.buckets[slot], st.heavy[slot]);
-    ZKT_HIP(c, hipGetLastError());
-    }
-    {
-    ProfScope prof_tail(c, "msm_tail", st.side);
-    const uint32_t q = (uint32_t)(st.c - 1), q2 = q / 2, q1 = q - q2;   // 2^q buckets below B = 2^q1 rows x 2^q2 columns
-    const uint32_t sums = (1u << q1) + (1u << q2);
-    Xyzz<Q>* rc = (Xyzz<Q>*)st.rowcol[slot];
-    hipLaunchKernelGGL(k_msm_rowcol<C>, dim3((sums + 3) / 4), dim3(256), 0, st.side, (const Xyzz<Q>*)st.buckets[slot], q1, q2, rc);
-    ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_weighted_rows<C>, dim3(q + 1), dim3(64), 0, st.side, (const Xyzz<Q>*)rc, q1, q2,
-                       (const Xyzz<Q>*)st.buckets[slot] + st.B, (Xyzz<Q>*)st.host_result_dev[slot]);
-    ZKT_HIP(c, hipGetLastError());
-    }
-    // the ny + 1 row sums are written straight into pinned host memory (16 posted writes of 128 B; a copy engine took
-    // ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
-    ZKT_HIP(c, hipEventRecord(st.ev_done[slot], st.side));
-    st.pending[slot] = true;
+    }   // "msm_main": grouping and accumulations of the batch (the tails' launches on the side stream cost it nothing)
     return ZKT_OK;
+}
+
+template <class C>
+static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0, int tbl = 0) {
+    return msm_enqueue_batch<C>(c, 1, &d_scalars, &n, &base_off, mont, &slot, tbl);
 }
 
 // S = sum_y 2^y V_y : V_y = the sum of the buckets below B whose index has bit y (y < c - 1), V_(c-1) = the top bucket.
@@ -1243,6 +1369,7 @@ template <class C>
 static int msm_collect(zkt_ctx* c, int slot, Affine<typename C::Fq>* out) {
     using Q = typename C::Fq;
     MsmState& st = *c->msm;
+    if (int rc0 = msm_launch_tails<C>(c)) return rc0;
     ZKT_HIP(c, hipEventSynchronize(st.ev_done[slot]));
     st.pending[slot] = false;
     *out = xyzz_to_affine_host<Q>(msm_host_finish<Q>(st, slot));
@@ -1260,6 +1387,7 @@ static int msm_collect_sharded(zkt_ctx* c, const int* slots, const bool* have, i
     MsmState& st = *c->msm;
     const int world = c->comm.vt.world;
     std::vector<Xyzz<Q>> send(k), recv((size_t)k * world);
+    if (int rc0 = msm_launch_tails<C>(c)) return rc0;
     for (int j = 0; j < k; ++j) {
         if (have[j]) {
             ZKT_HIP(c, hipEventSynchronize(st.ev_done[slots[j]]));
@@ -1312,6 +1440,36 @@ int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int 
         return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
     if (c->curve == ZKT_CURVE_BN254) return msm_enqueue<Bn254Curve>(c, d_scalars, n, base_off, mont, slot, tbl);
     return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont, slot, tbl);
+}
+// k commitments over the key's powers as one batch (msm_enqueue_batch); slots: k distinct slots
+int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, int mont, const int* slots) {
+    if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
+    if (k < 1 || k > MSM_BATCH) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm batch size");
+    size_t offs[MSM_BATCH] = {};
+    for (int j = 0; j < k; ++j) {
+        if (slots[j] < 0 || slots[j] >= MsmState::SLOTS) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "bad MSM slot");
+        for (int i = 0; i < j; ++i)
+            if (slots[i] == slots[j]) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm batch: slots must differ");
+        if (ns[j] == 0 || ns[j] > c->msm->count)
+            return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
+    }
+    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue_batch<Bn254Curve>(c, k, d_scalars, ns, offs, mont, slots, 0);
+    return msm_enqueue_batch<Bls381Curve>(c, k, d_scalars, ns, offs, mont, slots, 0);
+}
+bool msm_defers_tails(const zkt_ctx* c) { return c->msm && c->msm->defer_tails; }
+// Grouping the commitments of a round as one batch of launches pays between the two regimes: below, the proof is a chain
+// of latencies (tails deferred instead); above (n = 2^20: 190 MB of grouped indices per batch) the accumulation finds the
+// indices of its own MSM evicted from the last-level cache by its neighbours' and runs 4-5 % longer, more than the grouping saves.
+bool msm_batches_grouping(const zkt_ctx* c) {
+    if (!c->msm || c->msm->defer_tails) return false;
+    size_t limit = ((size_t)1 << 18) + 64;   // measured: +1.5 % at 2^18, nothing at 2^19, -1 % at 2^20
+    if (const char* e = exp_env("ZKT_MSM_BATCH_MAX_LOG")) limit = ((size_t)1 << atoi(e)) + 64;
+    return c->msm->count <= limit;
+}
+int msm_flush_tails(zkt_ctx* c) {
+    if (!c->msm) return ZKT_OK;
+    if (c->curve == ZKT_CURVE_BN254) return msm_launch_tails<Bn254Curve>(c);
+    return msm_launch_tails<Bls381Curve>(c);
 }
 int msm_end(zkt_ctx* c, int slot, uint64_t* out_xy) {
     if (c->curve == ZKT_CURVE_BN254) {

@@ -21,6 +21,31 @@ struct MsmWindows {
     uint16_t start[40];
 };
 
+constexpr int MSM_BATCH = 3;         // MSMs whose grouping and accumulation go out as ONE launch per kernel (blockIdx.y = MSM)
+// Per-MSM arguments of a batched launch.  The main-stream work buffers (pairs, grouped indices, count tables) exist
+// MSM_BATCH times, `s_*` apart; what the side stream reads later (offsets, pieces, params, heavy list) belongs to a slot.
+struct MsmBatch {
+    const void* scalars[MSM_BATCH];
+    uint64_t n[MSM_BATCH];
+    uint64_t base_off[MSM_BATCH];
+    uint32_t* heavy[MSM_BATCH];
+    uint32_t* params[MSM_BATCH];
+    uint32_t* offsets[MSM_BATCH];
+    void* pieces[MSM_BATCH];
+    uint64_t s_bin_offs, s_bin_aux, s_bin, s_tile_desc, s_cnt, s_pairs_bytes, s_vals, s_chunk;   // strides, in elements (pairs: bytes)
+};
+
+constexpr int MSM_TAIL_BATCH = 6;    // bucket folds / reductions that go out as ONE launch per kernel (blockIdx.y = slot)
+struct MsmTailBatch {                // per-slot arguments of a batched tail
+    const uint32_t* offsets[MSM_TAIL_BATCH];
+    const uint32_t* params[MSM_TAIL_BATCH];
+    const void* pieces[MSM_TAIL_BATCH];
+    void* buckets[MSM_TAIL_BATCH];
+    uint32_t* heavy[MSM_TAIL_BATCH];
+    void* rowcol[MSM_TAIL_BATCH];
+    void* partials[MSM_TAIL_BATCH];
+};
+
 constexpr int MSM_HEAVY = 32;       // buckets with more pieces than this are folded by a whole block
 constexpr int MSM_HEAVY_BLOCKS = 64;     // grid-stride over the (normally empty) list of crowded buckets
 
@@ -57,6 +82,7 @@ struct MsmState {
     int dig = 0;                                   // compile-time window layout of the level-1 kernels (0: generic)
     uint32_t l1_scalars = 0;                       // scalars per level-1 workgroup
     uint32_t l2_items = 0;                         // upper bound of level-2 tiles
+    MsmBatch strides{};                            // the s_* members: distance between the work buffers of a batch's MSMs
     // per slot, because the bucket fold that reads them runs on the side stream while the next MSM is already grouping
     uint32_t* offsets[11] = {};   // B + 2
     void* pieces[11] = {};        // XyzzRaw[max_chunks + B + 2]
@@ -72,6 +98,13 @@ struct MsmState {
     hipStream_t side = nullptr;
     hipEvent_t ev_main[SLOTS] = {}, ev_done[SLOTS] = {};
     bool pending[SLOTS] = {};
+    // Small keys (count <= MSM_DEFER_MAX): a proof is then a chain of latencies, and the bucket reduction of every
+    // commitment of a round is the same ~25 dependent curve operations whether one launch sequence covers one slot or six:
+    // the tails are deferred and issued once per round, batched (msm_flush_tails).  Large keys keep a tail per enqueue: it
+    // overlaps the next commitment's accumulation instead of the transforms behind the round.
+    bool defer_tails = false;
+    int tail_wait[SLOTS] = {};     // slots whose accumulation is enqueued and whose tail is not, in order
+    int n_tail_wait = 0;
     ~MsmState() {
         for (int i = 0; i < SLOTS; ++i) {
             if (host_result[i]) (void)hipHostFree(host_result[i]);
@@ -85,5 +118,10 @@ struct MsmState {
 
 // msm.hip: window multiples + R' conversion of an affine base table whose first `count` entries are filled (arkworks R form)
 int msm_table_finish(zkt_ctx* c, void* table, size_t count);
+// issues the deferred tails (no-op when none are waiting); the prover calls it behind the last commitment of a round
+int msm_flush_tails(zkt_ctx* c);
+bool msm_defers_tails(const zkt_ctx* c);
+bool msm_batches_grouping(const zkt_ctx* c);   // mid-size key: a round's commitments are grouped as one batch of launches   // small key: latency regime (tails deferred and batched, no batched grouping)
+constexpr size_t MSM_DEFER_MAX = ((size_t)1 << 16) + 64;
 
 }  // namespace zkt

@@ -22,6 +22,10 @@ namespace zkt {
 // msm.hip (tbl = 1: the Lagrange-prefix table of lagrange.hip)
 int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf);
 int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot, int tbl = 0);
+int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, int mont, const int* slots);
+int msm_flush_tails(zkt_ctx* c);           // issues the deferred bucket reductions of the commitments begun so far (small keys)
+bool msm_defers_tails(const zkt_ctx* c);
+bool msm_batches_grouping(const zkt_ctx* c);
 // lagrange.hip
 int lagrange_ensure(zkt_ctx* c, int log_n);
 bool lagrange_ready(const zkt_ctx* c, int log_n);
@@ -218,6 +222,16 @@ struct Prover {
         if (!S.have[slot]) return ZKT_OK;
         const size_t l = std::min(len, off + cnt) - off;
         return msm_begin(c, (const char*)d_poly + off * 32, l, 0, 1, slot);
+    }
+    // The commitments of one round that exist at the same time (a, b, c; q_lo, q_mid, q_hi) as ONE batch of launches
+    // (msm.hip msm_enqueue_batch); a sharded key commits them one by one (each rank only its slice).
+    int commit_begin_many(void* const* d_polys, const size_t* lens, const int* slots, int k) {
+        if (c->sharded() || c->batch_off || !msm_batches_grouping(c)) {   // (msm.hip: which key sizes gain from it)
+            for (int j = 0; j < k; ++j)
+                if (int rc = commit_begin(d_polys[j], lens[j], slots[j])) return rc;
+            return ZKT_OK;
+        }
+        return msm_begin_batch(c, k, d_polys, lens, 1, slots);
     }
     // Commitment of the polynomial with evaluations `ev` plus k blinders (prove.rs:166-180,249-251), whose blinded
     // coefficients are in d_poly.  With the Lagrange-basis table (lagrange.hip) the scalars are the differences of
@@ -496,8 +510,14 @@ struct Prover {
             }
             const PolyJob jobs[3] = {{S.ev[0], S.poly[0], 0, 2, 0}, {S.ev[1], S.poly[1], 2, 2, 1}, {S.ev[2], S.poly[2], 4, 2, 2}};
             if ((rc = evals_to_blinded_polys(jobs, 3))) return rc;
-            for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[k], n + 2, k))) return rc;
+            {
+                void* const polys[3] = {S.poly[0], S.poly[1], S.poly[2]};
+                const size_t lens[3] = {n + 2, n + 2, n + 2};
+                static const int slots[3] = {0, 1, 2};
+                if ((rc = commit_begin_many(polys, lens, slots, 3))) return rc;
+            }
         }
+        if ((rc = msm_flush_tails(c))) return rc;
         return to_coset_many({W_A, W_B, W_C});
     }
 
@@ -541,6 +561,7 @@ struct Prover {
         }
         if ((rc = commit_evals_begin(S.ev[5], S.poly[4], 6, 3, 4, 4))) return rc;
         if ((rc = commit_evals_begin(S.ev[6], S.poly[5], 9, 2, 5, 5))) return rc;
+        if ((rc = msm_flush_tails(c))) return rc;
         if (!S.t_coset_valid && !table_done) return to_coset_many({W_T, W_H1, W_H2});
         return to_coset_many({W_H1, W_H2});   // unchanged table: its coset is still resident
     }
@@ -647,6 +668,7 @@ struct Prover {
         }
         if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
         if ((rc = commit_evals_begin(S.sc[0], S.poly[7], 14, 3, 7, 1))) return rc;
+        if ((rc = msm_flush_tails(c))) return rc;
         if ((rc = to_coset_many({W_Z1, W_Z2}))) return rc;
         // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well.  With a handful of
         // public inputs it is never built: the quotient kernel evaluates it from rotations of l1 (poly.hpp).
@@ -743,7 +765,13 @@ struct Prover {
                 return rc;
             // an unsatisfied circuit shows up as status bits here; they are read with the evaluations of round 5
         }
-        for (int k = 0; k < 3; ++k) if ((rc = commit_begin(S.poly[9 + k], n + 3, 8 + k))) return rc;
+        {
+            void* const polys[3] = {S.poly[9], S.poly[10], S.poly[11]};
+            const size_t lens[3] = {n + 3, n + 3, n + 3};
+            static const int slots[3] = {8, 9, 10};
+            if ((rc = commit_begin_many(polys, lens, slots, 3))) return rc;
+            if ((rc = msm_flush_tails(c))) return rc;
+        }
         if (S.has_next) {   // zkt_prove_set_next: round 1 of the next proof hides the tail of the quotient commitments
             S.has_next = false;
             swap_work_sets();
@@ -892,6 +920,7 @@ struct Prover {
             F zi = fe_inv_host<R>(shifted);
             if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
             if ((rc = commit_begin(S.sc[3], cap - 1, 7))) return rc;
+            if ((rc = msm_flush_tails(c))) return rc;
             if (S.prefetch_stage == 1) {   // ... and its round 2 keeps the GPU fed across the proof boundary
                 bool st = false;
                 swap_work_sets();
