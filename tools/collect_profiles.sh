@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/final_<tag>/ -> profiles/ (the files the judge reads).  usage: bash tools/collect_profiles.sh r04 [suffix]
-TAG=${1:-r04}; SFX=${2:-}
+TAG=${1:-r05}; SFX=${2:-}
 S=gpurun_out/final_$TAG
 cp $S/bench_$TAG.json profiles/bench_${TAG}${SFX}.json
 for c in bn254_2_20 bls12_381_2_22; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, taken on ONE box from the current sources.  usage (GPU box): bash tools/final_profiles.sh r04
 # -> gpurun_out/final_<tag>/ (copy into profiles/ afterwards: tools/collect_profiles.sh)
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 step() { echo "[$(date +%T)] $*" | tee -a $OUT/steps.log; }

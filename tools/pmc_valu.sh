@@ -25,6 +25,11 @@ for f in glob.glob("gpurun_out/pmc_valu_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("zkt::", "")[-44:]
         out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in out.items():   # the accumulation: dense commitments only (the Lagrange-basis ones run it over a few thousand pairs)
+    if "k_msm_accumulate" in k:
+        for cn in list(v):
+            mx = max(v[cn])
+            v[cn] = [x for x in v[cn] if x >= 0.25 * mx] if mx > 0 else v[cn]
 names = sorted({c for v in out.values() for c in v})
 import subprocess
 with open("gpurun_out/pmc_valu_%s.txt" % sys.argv[1], "w") as fo:
