@@ -58,6 +58,16 @@ enum {
  * GPU is present: there is no CPU fallback. */
 int zkt_ctx_create(int curve_id, int device_id, zkt_ctx** out);
 void zkt_ctx_destroy(zkt_ctx* ctx);
+/* A second context on the same GPU that SHARES `ctx`'s read-only tables -- the SRS window table and the Lagrange-basis
+ * table, the circuit's keys (ProverKey polynomials, ExtendedProverKey cosets), the transform twiddles -- and owns only
+ * what a proof writes: its stream, work buffers and MSM slots (about 3 of the ~7 GiB a context holds at n = 2^20).  For a
+ * service that keeps several proofs in flight on one GPU (one host thread per context), which is what hides the latency
+ * chain of the reference's real circuit sizes: n = 2^14 309 -> 460 proofs/s, n = 2^18 155 -> 177 with two or three
+ * contexts.  The fork proves exactly as `ctx` would (same bytes).  Rules: no communicator on either side; while forks are
+ * alive `ctx` refuses zkt_srs_* / zkt_circuit_* / zkt_ctx_set_comm (its tables are in use), and zkt_ctx_destroy(ctx) takes
+ * effect when the last fork is destroyed; a fork that loads a key or circuit of its own simply stops sharing that part.
+ * Create and destroy contexts from one thread (or serialise those calls); prove on them concurrently. */
+int zkt_ctx_fork(zkt_ctx* ctx, zkt_ctx** out);
 const char* zkt_last_error(const zkt_ctx* ctx);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) for every launch of this context. */
 int zkt_ctx_set_stream(zkt_ctx* ctx, void* hip_stream);

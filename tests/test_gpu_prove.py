@@ -834,3 +834,65 @@ def test_contexts_in_flight_prove_the_same_bytes(cvname, gates):
         th.join(timeout=900)
     assert not errors, errors
     assert got == want
+
+
+@pytest.mark.parametrize("cvname,gates", [("bn254", 3000), ("bls12_381", 900)])
+def test_forked_contexts_share_tables_and_prove_the_same_bytes(cvname, gates):
+    """zkt_ctx_fork: contexts that share one context's SRS / Lagrange / circuit / twiddle tables and own only their work
+    buffers.  The parent and two forks prove different proofs concurrently (one thread each): the oracle's bytes everywhere.
+    Lifetime rules: a parent with live forks refuses to reload its key or circuit; destroyed first it lingers until its last
+    fork is gone (the forks keep proving); a fork that loads its own key stops sharing and still proves the same bytes."""
+    import threading
+    import zkt_plonk_amd as z
+    cv = F.CURVES[cvname]
+    cs = P.synthetic_circuit(cv, gates, 64, seed=gates + 5)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, 0xF04C + gates, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    pkm = {k: K.fr_to_mont(cv, pk.polys[k]) if pk.polys[k] else np.zeros((0, 4), dtype=np.uint64) for k in z.PK_ORDER}
+    a, b, c = (K.fr_to_mont(cv, w) for w in cs.wire_evals(cs.n_gates))
+    pi_pos = sorted(cs.pi)
+    pi_vals = K.fr_to_mont(cv, [cs.pi[k] for k in pi_pos])
+    table = K.fr_to_mont(cv, cs.table)
+    bl = [field_elems(cv.fr.p, 7700 + t, P.NUM_BLINDERS) for t in range(3)]
+    want = [P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), x).serialize(cv) for x in bl]
+
+    def tr():
+        return z.seed_transcript(z.Transcript("merlin", "ZKT Plonk", fr_bits=cv.fr.bits, fq_bytes=cv.fq.limbs64 * 8), vk.n, vk.commits)
+
+    parent = z.Context(cv.name, 0)
+    parent.srs_load(srs_arr)
+    z.GpuProver(parent, n.bit_length() - 1, pkm)
+    assert parent.prove(a, b, c, table, pi_pos, pi_vals, K.fr_to_mont(cv, bl[0]), tr()) == want[0]   # builds the Lagrange table
+    forks = [parent.fork(), parent.fork()]
+    ctxs3 = [parent] + forks
+    for f in forks:
+        assert f.lagrange_info() == parent.lagrange_info() and f.msm_info() == parent.msm_info()
+    with pytest.raises(z.ZktError):
+        parent.srs_load(srs_arr)                  # its tables are in use
+    with pytest.raises(z.ZktError):
+        z.GpuProver(parent, n.bit_length() - 1, pkm)
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(3):
+                got = ctxs3[t].prove(a, b, c, table, pi_pos, pi_vals, K.fr_to_mont(cv, bl[t]), tr())
+                assert got == want[t], t
+        except BaseException as e:
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=600)
+    assert not errors, errors
+    parent.close()                                # lingers: the forks still read its tables
+    assert forks[0].prove(a, b, c, table, pi_pos, pi_vals, K.fr_to_mont(cv, bl[1]), tr()) == want[1]
+    forks[1].srs_load(srs_arr)                    # a key of its own: stops sharing that part, same bytes
+    assert forks[1].prove(a, b, c, table, pi_pos, pi_vals, K.fr_to_mont(cv, bl[2]), tr()) == want[2]
+    forks[0].close()
+    assert forks[1].prove(a, b, c, table, pi_pos, pi_vals, K.fr_to_mont(cv, bl[0]), tr()) == want[0]
+    forks[1].close()                              # the last fork: the parent goes with it

@@ -497,6 +497,16 @@ class Context:
             raise ZktError(rc, "zkt_ctx_create failed (no GPU? there is no CPU fallback)")
         self._h = h
 
+    def fork(self) -> "Context":
+        """zkt_ctx_fork: a context sharing this one's key / circuit / twiddle tables, with its own stream and work buffers."""
+        self._L.zkt_ctx_fork.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        h = ctypes.c_void_p()
+        self.check(self._L.zkt_ctx_fork(self._h, ctypes.byref(h)))
+        other = Context.__new__(Context)
+        other.__dict__.update(self.__dict__)
+        other._h = h
+        return other
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.zkt_ctx_destroy(self._h)

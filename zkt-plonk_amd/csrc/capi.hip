@@ -12,6 +12,9 @@ namespace zkt {
 
 void circuit_release(zkt_ctx* c);   // prover.hip
 void msm_release(zkt_ctx* c);       // msm.hip
+// msm.hip / prover.hip: a state of its own over the parent's read-only tables (zkt_ctx_fork)
+int msm_fork(zkt_ctx* child, const zkt_ctx* parent);
+int circuit_fork(zkt_ctx* child, const zkt_ctx* parent);
 
 const char* exp_env(const char* name) {
 #ifdef ZKT_EXPERIMENTS
@@ -25,6 +28,11 @@ const char* exp_env(const char* name) {
 int set_err(zkt_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
+}
+int refuse_if_forked(zkt_ctx* c, const char* what) {
+    if (c && c->forks.load() > 0)
+        return set_err(c, ZKT_ERR_INVALID_ARGUMENT, std::string(what) + ": contexts forked from this one still use its tables (destroy them first)");
+    return ZKT_OK;
 }
 int hip_fail(zkt_ctx* c, hipError_t e, const char* what) {
     return set_err(c, ZKT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -201,10 +209,41 @@ int zkt_ctx_create(int curve_id, int device_id, zkt_ctx** out) {
     return ZKT_OK;
 }
 
+int zkt_ctx_fork(zkt_ctx* parent, zkt_ctx** out) {
+    if (!parent || !out) return ZKT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (parent->sharded()) return set_err(parent, ZKT_ERR_INVALID_ARGUMENT, "zkt_ctx_fork: not for a context with a communicator");
+    if (parent->zombie) return set_err(parent, ZKT_ERR_INVALID_ARGUMENT, "zkt_ctx_fork: the context has been destroyed");
+    zkt_ctx* root = parent->parent ? parent->parent : parent;   // forks of a fork hang off the owner of the tables
+    zkt_ctx* c = nullptr;
+    int rc = zkt_ctx_create(parent->curve, parent->device, &c);
+    if (rc) return rc;
+    (void)hipStreamSynchronize(parent->stream);   // the tables are complete
+    c->lagrange_off = parent->lagrange_off;
+    c->batch_off = parent->batch_off;
+    c->ntt_plans = parent->ntt_plans;             // twiddle tables: immutable, owned by the root
+    c->parent = root;
+    root->forks.fetch_add(1);
+    if ((rc = msm_fork(c, parent)) || (rc = circuit_fork(c, parent))) {
+        parent->err = c->err;
+        zkt_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ZKT_OK;
+}
+
 void zkt_ctx_destroy(zkt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->forks.load() > 0) {   // forks still read this context's tables: linger until the last of them is gone
+        c->zombie = true;
+        return;
+    }
+    zkt_ctx* const owner = c->parent;
+    circuit_release(c);
+    msm_release(c);
     prof_resolve(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->event_pool.clear();
@@ -216,10 +255,16 @@ void zkt_ctx_destroy(zkt_ctx* c) {
     c->owned.clear();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    if (owner && owner->forks.fetch_sub(1) == 1 && owner->zombie) {
+        owner->zombie = false;
+        zkt_ctx_destroy(owner);
+    }
 }
 
 int zkt_ctx_set_comm(zkt_ctx* c, const zkt_comm_vtable* comm) {
     if (!c) return ZKT_ERR_INVALID_ARGUMENT;
+    if (int rf = refuse_if_forked(c, "zkt_ctx_set_comm")) return rf;
+    if (c->parent && comm && comm->world > 1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "a forked context cannot take a communicator");
     if (comm && comm->world > 1) {
         const int w = comm->world;
         if ((w != 2 && w != 4 && w != 8) || comm->rank < 0 || comm->rank >= w || !comm->all_gather)

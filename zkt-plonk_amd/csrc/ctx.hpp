@@ -8,6 +8,7 @@
 #include <tuple>
 #include <vector>
 #include <memory>
+#include <atomic>
 
 #include "../../include/zkt_plonk.h"
 #include "fp.hpp"
@@ -61,6 +62,11 @@ struct zkt_ctx {
     std::shared_ptr<zkt::MsmState> msm;
     uint64_t msm_epoch = 0;   // bumped by every MSM enqueue and SRS (re)load: work issued ahead of time is tied to it
     uint64_t srs_generation = 0;   // bumped by every SRS (re)load: cached commitments are tied to the key they were made under
+    // zkt_ctx_fork: forks share this context's read-only tables.  A parent with live forks refuses to reload them; when it
+    // is destroyed first it lingers (zombie) until its last fork is gone.
+    zkt_ctx* parent = nullptr;
+    std::atomic<int> forks{0};
+    bool zombie = false;
     bool batch_off = false;        // A/B builds: ZKT_MSM_NO_BATCH commits a round's polynomials one launch sequence each
     bool lagrange_off = false;     // zkt_ctx_set_lagrange(ctx, 0): evaluations are committed through their coefficients
     std::shared_ptr<zkt::CircuitState> circuit;
@@ -75,6 +81,8 @@ namespace zkt {
 const char* exp_env(const char* name);
 
 int set_err(zkt_ctx* c, int code, const std::string& msg);
+// ZKT_ERR_INVALID_ARGUMENT when forks of `c` are alive (their tables are c's)
+int refuse_if_forked(zkt_ctx* c, const char* what);
 int hip_fail(zkt_ctx* c, hipError_t e, const char* what);
 
 #define ZKT_HIP(c, call)                                        \

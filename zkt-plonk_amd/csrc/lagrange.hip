@@ -214,7 +214,8 @@ static int lagrange_build_t(zkt_ctx* c, int log_n) {
                            (Affine<Q>*)table2);
     if (hipGetLastError() != hipSuccess) return release(set_err(c, ZKT_ERR_HIP, "Lagrange key: launch failed"));
     if ((rc = msm_table_finish(c, table2, count2))) return release(rc);   // synchronises: `pre` may go
-    dev_free(c, st.table2);
+    if (!st.table2_borrowed) dev_free(c, st.table2);
+    st.table2_borrowed = false;
     st.table2 = table2;
     st.count2 = count2;
     st.lag_log_n = log_n;
@@ -231,7 +232,8 @@ int lagrange_ensure(zkt_ctx* c, int log_n) {
     const size_t n = (size_t)1 << log_n;
     const bool whole_key = !c->sharded() && st.slice_off == 0 && st.total == st.count;
     if (!whole_key || st.count <= n || log_n > 30 || (uint64_t)st.W * (n + LAG_MAX_EXTRA) >= ((uint64_t)1 << 31)) {
-        dev_free(c, st.table2);
+        if (!st.table2_borrowed) dev_free(c, st.table2);
+        st.table2_borrowed = false;
         st.table2 = nullptr;
         st.count2 = 0;
         st.lag_log_n = log_n;

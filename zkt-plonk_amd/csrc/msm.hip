@@ -929,7 +929,7 @@ static int floor_log2(size_t x) {
 }
 
 template <class C>
-static int msm_setup(zkt_ctx* c, size_t count) {
+static int msm_setup(zkt_ctx* c, size_t count, const MsmState* share = nullptr) {
     using Q = typename C::Fq;
     using R = typename C::Fr;
     auto st = std::make_shared<MsmState>();
@@ -971,7 +971,19 @@ static int msm_setup(zkt_ctx* c, size_t count) {
     if ((uint64_t)st->W * count >= ((uint64_t)1 << 31))
         return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "SRS too large for 31-bit table indices");
     int rc;
-    if ((rc = dev_alloc(c, &st->table, (size_t)st->W * count * sizeof(Affine<Q>)))) return rc;
+    if (share) {   // zkt_ctx_fork: the parent's tables (same count, hence the same layout), everything below this context's own
+        st->table = share->table;
+        st->table_borrowed = true;
+        st->table2 = share->table2;
+        st->table2_borrowed = share->table2 != nullptr;
+        st->count2 = share->count2;
+        st->lag_log_n = share->lag_log_n;
+        st->lag_failed = share->lag_failed;
+        st->slice_off = share->slice_off;
+        st->total = share->total;
+    } else if ((rc = dev_alloc(c, &st->table, (size_t)st->W * count * sizeof(Affine<Q>)))) {
+        return rc;
+    }
     size_t m = (size_t)st->W * count;
     // the main-stream work buffers exist MSM_BATCH times (a round's commitments are grouped and accumulated as one batch:
     // msm_enqueue_batch); strides between the copies in st->strides
@@ -1099,6 +1111,16 @@ template <class C>
 static int srs_finish(zkt_ctx* c) {
     return table_finish<C>(c, c->msm->table, c->msm->count);
 }
+void msm_release(zkt_ctx* c);
+int msm_fork(zkt_ctx* child, const zkt_ctx* parent) {
+    msm_release(child);
+    if (!parent->msm) return ZKT_OK;
+    int rc = parent->curve == ZKT_CURVE_BN254 ? msm_setup<Bn254Curve>(child, parent->msm->count, parent->msm.get())
+                                               : msm_setup<Bls381Curve>(child, parent->msm->count, parent->msm.get());
+    if (rc) return rc;
+    child->srs_generation = parent->srs_generation;
+    return ZKT_OK;
+}
 int msm_table_finish(zkt_ctx* c, void* table, size_t count) {
     if (c->curve == ZKT_CURVE_BN254) return table_finish<Bn254Curve>(c, table, count);
     return table_finish<Bls381Curve>(c, table, count);
@@ -1109,8 +1131,8 @@ void msm_release(zkt_ctx* c) {
     MsmState& st = *c->msm;
     (void)hipStreamSynchronize(c->stream);
     if (st.side) (void)hipStreamSynchronize(st.side);
-    void* ptrs[] = {st.table,     st.table2, st.vals2, st.pairs, st.bin_offs, st.bin_aux, st.bin_start,
-                    st.tile_start, st.cnt2,   st.pos2,  st.chunk_bucket, st.tile_desc};
+    void* ptrs[] = {st.table_borrowed ? nullptr : st.table, st.table2_borrowed ? nullptr : st.table2, st.vals2, st.pairs,
+                    st.bin_offs, st.bin_aux, st.bin_start, st.tile_start, st.cnt2, st.pos2, st.chunk_bucket, st.tile_desc};
     for (void* p : ptrs) dev_free(c, p);
     for (int i = 0; i < MsmState::SLOTS; ++i) {
         dev_free(c, st.heavy[i]); dev_free(c, st.offsets[i]); dev_free(c, st.pieces[i]); dev_free(c, st.params[i]);
@@ -1123,6 +1145,7 @@ template <class C>
 static int srs_load_t(zkt_ctx* c, const void* src, size_t count, bool src_on_device, size_t slice_off = 0, size_t total = 0) {
     using Q = typename C::Fq;
     if (count == 0) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "empty SRS");
+    if (int rf = refuse_if_forked(c, "loading a key")) return rf;
     msm_release(c);
     int rc = msm_setup<C>(c, count);
     if (rc) return rc;
@@ -1173,6 +1196,7 @@ static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t
     using Q = typename C::Fq;
     using R = typename C::Fr;
     if (count == 0) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "empty SRS");
+    if (int rf = refuse_if_forked(c, "loading a key")) return rf;
     msm_release(c);
     int rc = msm_setup<C>(c, count);
     if (rc) return rc;

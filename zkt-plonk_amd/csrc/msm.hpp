@@ -65,6 +65,8 @@ struct MsmState {
     size_t count2 = 0;
     int lag_log_n = -1;
     bool lag_failed = false;       // the key is too short (or sharded): evaluations are committed through their coefficients
+    // zkt_ctx_fork: the base tables belong to the context this one was forked from (read-only here, never freed here)
+    bool table_borrowed = false, table2_borrowed = false;
     uint32_t* params[11] = {};     // per slot, device: [0] chunk, [1] pairs (written by k_msm_scan_aux)
     // work buffers (sized for n = count)
     uint32_t* vals2 = nullptr;                     // table indices grouped by bucket
@@ -118,6 +120,8 @@ struct MsmState {
 
 // msm.hip: window multiples + R' conversion of an affine base table whose first `count` entries are filled (arkworks R form)
 int msm_table_finish(zkt_ctx* c, void* table, size_t count);
+// msm.hip: `child` gets an MSM state of its own (work buffers, slots, side stream) over `parent`'s base tables
+int msm_fork(zkt_ctx* child, const zkt_ctx* parent);
 // issues the deferred tails (no-op when none are waiting); the prover calls it behind the last commitment of a round
 int msm_flush_tails(zkt_ctx* c);
 bool msm_defers_tails(const zkt_ctx* c);

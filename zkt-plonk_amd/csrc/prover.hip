@@ -97,6 +97,8 @@ struct CircuitState {
     bool t_cached = false, t_coset_valid = false;
     uint64_t t_srs_generation = 0;   // zkt_ctx::srs_generation the cached commitment was made under
     uint64_t t_commit_xy[12] = {};
+    // zkt_ctx_fork: the keys (pk, coset, sigma_ev, q_lookup_ev, roots) belong to the context this one was forked from
+    bool keys_borrowed = false;
 };
 
 // ---- host field helpers ------------------------------------------------------------------------------
@@ -971,10 +973,12 @@ void circuit_release(zkt_ctx* c) {
     CircuitState& S = *c->circuit;
     if (S.copy_stream) (void)hipStreamSynchronize(S.copy_stream);
     auto fr = [&](void* p) { dev_free(c, p); };
-    for (void* p : S.pk) fr(p);
-    for (void* p : S.coset) fr(p);
-    for (void* p : S.sigma_ev) fr(p);
-    fr(S.q_lookup_ev); fr(S.roots);
+    if (!S.keys_borrowed) {
+        for (void* p : S.pk) fr(p);
+        for (void* p : S.coset) fr(p);
+        for (void* p : S.sigma_ev) fr(p);
+        fr(S.q_lookup_ev); fr(S.roots);
+    }
     for (void* p : S.ev) fr(p);
     for (void* p : S.sc) fr(p);
     fr(S.scan_tmp);
@@ -1001,56 +1005,18 @@ void circuit_release(zkt_ctx* c) {
     c->circuit.reset();
 }
 
-template <class C>
-static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, const size_t* lens, bool from_evals = false,
-                          bool from_evals_on_device = false) {
-    using R = typename C::Fr;
-    using F = Fe<R>;
-    if (log_n < 3 || log_n + 2 > R::TWO_ADICITY || log_n + 2 > 27)
-        return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize: 4n domain unsupported");
-    circuit_release(c);
-    auto st = std::make_shared<CircuitState>();
-    CircuitState& S = *st;
-    S.log_n = log_n;
-    const size_t n = (size_t)1 << log_n;
-    S.n = n;
-    // sharded proof: this GPU keeps (and later transforms) only its class of the 4n coset
-    S.G = c->sharded() ? c->comm.vt.world : 1;
-    S.cls = c->sharded() ? c->comm.vt.rank : 0;
-    S.log_m = log_n + 2 - (S.G == 8 ? 3 : S.G == 4 ? 2 : S.G == 2 ? 1 : 0);
-    S.m = (size_t)1 << S.log_m;
-    const size_t m = S.m;
+// Everything a context needs PER PROOF (work buffers, staging, streams, events) for the circuit shape in S (log_n, G, cls
+// set): what a forked context allocates for itself while the keys stay its parent's.
+static int circuit_alloc_work(zkt_ctx* c, CircuitState& S) {
+    const size_t n = S.n, m = S.m;
     int rc;
     auto alloc = [&](void** p, size_t elems) { return dev_alloc(c, p, elems * 32); };
     if ((rc = alloc(&S.qev, 4 * n))) return rc;
-    for (int k = 0; k < PK_COUNT; ++k) {
-        if (lens[k] > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "prover-key polynomial longer than n");
-        if ((rc = alloc(&S.pk[k], n))) return rc;
-        if (from_evals) {
-            // setup.rs:72-90: poly_from_evals of the padded selector / sigma / table-mask evaluations
-            const void* src = polys[k];
-            if (!from_evals_on_device) {
-                ZKT_HIP(c, hipMemsetAsync(S.qev, 0, n * 32, c->stream));   // the quotient vector doubles as staging
-                if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.qev, polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
-                src = S.qev;
-            }
-            if ((rc = ntt_run(c, log_n, 1, 0, src, from_evals_on_device ? lens[k] : n, S.pk[k]))) return rc;
-            S.pk_len[k] = n;
-        } else {
-            ZKT_HIP(c, hipMemsetAsync(S.pk[k], 0, n * 32, c->stream));
-            if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.pk[k], polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
-            S.pk_len[k] = lens[k];
-        }
-    }
-    for (int k = 0; k < CS_COUNT; ++k) if ((rc = alloc(&S.coset[k], m))) return rc;
     if (S.G > 1) {
         if ((rc = alloc(&S.fold, m))) return rc;
         if ((rc = alloc(&S.qgather, 4 * n))) return rc;
         if (S.G == 8) for (auto& p : S.wnext) if ((rc = alloc(&p, m))) return rc;
     }
-    for (int k = 0; k < 3; ++k) if ((rc = alloc(&S.sigma_ev[k], n))) return rc;
-    if ((rc = alloc(&S.q_lookup_ev, n))) return rc;
-    if ((rc = alloc(&S.roots, n))) return rc;
     for (auto& p : S.ev) if ((rc = alloc(&p, n + 8))) return rc;
     for (auto& p : S.sc) if ((rc = alloc(&p, n + 8))) return rc;
     if ((rc = alloc(&S.scan_tmp, 2 * ((n + 8) / 1024 + 4096)))) return rc;
@@ -1077,6 +1043,77 @@ static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, c
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
     if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * (257 + eval_blocks)))) return rc;
+    return ZKT_OK;
+}
+
+// zkt_ctx_fork: the parent's keys (ProverKey polynomials, ExtendedProverKey cosets, sigma / q_lookup evaluations, domain
+// roots: all read-only for a prover), this context's own work set
+int circuit_fork(zkt_ctx* child, const zkt_ctx* parent) {
+    circuit_release(child);
+    if (!parent->circuit) return ZKT_OK;
+    const CircuitState& P0 = *parent->circuit;
+    auto st = std::make_shared<CircuitState>();
+    CircuitState& S = *st;
+    S.log_n = P0.log_n; S.n = P0.n; S.G = P0.G; S.cls = P0.cls; S.log_m = P0.log_m; S.m = P0.m;
+    for (int k = 0; k < PK_COUNT; ++k) { S.pk[k] = P0.pk[k]; S.pk_len[k] = P0.pk_len[k]; }
+    for (int k = 0; k < CS_COUNT; ++k) S.coset[k] = P0.coset[k];
+    for (int k = 0; k < 3; ++k) S.sigma_ev[k] = P0.sigma_ev[k];
+    S.q_lookup_ev = P0.q_lookup_ev;
+    S.roots = P0.roots;
+    memcpy(S.zh_inv, P0.zh_inv, sizeof(S.zh_inv));
+    S.keys_borrowed = true;
+    child->circuit = st;                      // from here on circuit_release cleans up after a failure
+    const int rc = circuit_alloc_work(child, S);
+    if (rc) circuit_release(child);
+    return rc;
+}
+
+template <class C>
+static int circuit_load_t(zkt_ctx* c, int log_n, const uint64_t* const* polys, const size_t* lens, bool from_evals = false,
+                          bool from_evals_on_device = false) {
+    using R = typename C::Fr;
+    using F = Fe<R>;
+    if (log_n < 3 || log_n + 2 > R::TWO_ADICITY || log_n + 2 > 27)
+        return set_err(c, ZKT_ERR_INVALID_DOMAIN_SIZE, "InvalidEvalDomainSize: 4n domain unsupported");
+    if (int rf = refuse_if_forked(c, "loading a circuit")) return rf;
+    circuit_release(c);
+    auto st = std::make_shared<CircuitState>();
+    CircuitState& S = *st;
+    S.log_n = log_n;
+    const size_t n = (size_t)1 << log_n;
+    S.n = n;
+    // sharded proof: this GPU keeps (and later transforms) only its class of the 4n coset
+    S.G = c->sharded() ? c->comm.vt.world : 1;
+    S.cls = c->sharded() ? c->comm.vt.rank : 0;
+    S.log_m = log_n + 2 - (S.G == 8 ? 3 : S.G == 4 ? 2 : S.G == 2 ? 1 : 0);
+    S.m = (size_t)1 << S.log_m;
+    const size_t m = S.m;
+    int rc;
+    auto alloc = [&](void** p, size_t elems) { return dev_alloc(c, p, elems * 32); };
+    if ((rc = circuit_alloc_work(c, S))) return rc;   // (the quotient vector doubles as staging below)
+    for (int k = 0; k < PK_COUNT; ++k) {
+        if (lens[k] > n) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "prover-key polynomial longer than n");
+        if ((rc = alloc(&S.pk[k], n))) return rc;
+        if (from_evals) {
+            // setup.rs:72-90: poly_from_evals of the padded selector / sigma / table-mask evaluations
+            const void* src = polys[k];
+            if (!from_evals_on_device) {
+                ZKT_HIP(c, hipMemsetAsync(S.qev, 0, n * 32, c->stream));   // the quotient vector doubles as staging
+                if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.qev, polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
+                src = S.qev;
+            }
+            if ((rc = ntt_run(c, log_n, 1, 0, src, from_evals_on_device ? lens[k] : n, S.pk[k]))) return rc;
+            S.pk_len[k] = n;
+        } else {
+            ZKT_HIP(c, hipMemsetAsync(S.pk[k], 0, n * 32, c->stream));
+            if (lens[k]) ZKT_HIP(c, hipMemcpyAsync(S.pk[k], polys[k], lens[k] * 32, hipMemcpyHostToDevice, c->stream));
+            S.pk_len[k] = lens[k];
+        }
+    }
+    for (int k = 0; k < CS_COUNT; ++k) if ((rc = alloc(&S.coset[k], m))) return rc;
+    for (int k = 0; k < 3; ++k) if ((rc = alloc(&S.sigma_ev[k], n))) return rc;
+    if ((rc = alloc(&S.q_lookup_ev, n))) return rc;
+    if ((rc = alloc(&S.roots, n))) return rc;
 
     // extend_prover_key (keys/mod.rs:78-146) on the device
     const int pk_of_cs[10] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, PK_QLOOKUP, PK_QTABLE, PK_S1, PK_S2, PK_S3};
