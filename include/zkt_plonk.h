@@ -206,7 +206,7 @@ int zkt_msm_info(zkt_ctx* ctx, int* window_bits, int* windows, size_t* srs_count
  *     commit = sum_k (e_(k-1) - e_k) S_k + sum_j b_j ([tau^(n+j)] G - [tau^j] G),
  * an MSM whose scalars vanish inside every run.  The same group element, so the same proof bytes; a dense vector costs
  * what its coefficients would.  The second base table (prefix sums of the inverse DFT of the powers over G1, plus the
- * blinder points; as large as the first) is built on the first proof after a key or circuit change -- about 0.3 s at
+ * blinder points; as large as the first) is built on the first proof after a key or circuit change -- about 0.55 s at
  * n = 2^20 on BN254 -- when the key is whole (not a slice of a sharded key) and holds more than n powers; otherwise,
  * or after zkt_ctx_set_lagrange(ctx, 0), the coefficients are committed as the reference does. */
 int zkt_ctx_set_lagrange(zkt_ctx* ctx, int on);

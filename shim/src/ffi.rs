@@ -64,6 +64,7 @@ extern "C" {
     pub fn zkt_srs_load_file(ctx: *mut ZktCtx, ck_path: *const c_char, max_powers: usize) -> c_int;
     pub fn zkt_msm_g1(ctx: *mut ZktCtx, scalars: *const u64, len: usize, base_offset: usize, scalars_montgomery: c_int,
                       out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
+    pub fn zkt_ctx_fork(ctx: *mut ZktCtx, out: *mut *mut ZktCtx) -> c_int;
     pub fn zkt_commit_evals_dev(ctx: *mut ZktCtx, d_evals: *const c_void, blinders: *const u64, k: c_int, path: c_int,
                                 out_xy_mont: *mut u64, out_is_infinity: *mut c_int) -> c_int;
     pub fn zkt_ctx_set_lagrange(ctx: *mut ZktCtx, on: c_int) -> c_int;

@@ -14,7 +14,7 @@
 // V_j = [tau^(n+j)] G - [tau^j] G.
 //
 // This file builds that second base table once per (key, domain size): the inverse DFT over G1 (radix-2 DIF, one scalar
-// multiplication per butterfly: (n/2) log n of them, ~0.3 s at n = 2^20 on BN254), the prefix sums, the blinder points,
+// multiplication per butterfly: (n/2) log n of them, ~0.5 s at n = 2^20 on BN254), the prefix sums, the blinder points,
 // then the window multiples exactly as for the powers (msm_table_finish).  1/n is NOT applied to the points: the scalars
 // carry it (poly.hip k_lagrange_scalars).  The table holds R^-1-scaled bases like the first one (msm.hip header), which
 // is free here: the transform is linear and starts from table[0].
