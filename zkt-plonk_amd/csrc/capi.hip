@@ -198,6 +198,7 @@ int zkt_ctx_create(int curve_id, int device_id, zkt_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess) return ZKT_ERR_NO_DEVICE;
     zkt_ctx* c = new zkt_ctx();
     c->batch_off = exp_env("ZKT_MSM_NO_BATCH") != nullptr;
+    c->aux_off = exp_env("ZKT_NO_AUX") != nullptr;
     c->curve = curve_id;
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -221,6 +222,7 @@ int zkt_ctx_fork(zkt_ctx* parent, zkt_ctx** out) {
     (void)hipStreamSynchronize(parent->stream);   // the tables are complete
     c->lagrange_off = parent->lagrange_off;
     c->batch_off = parent->batch_off;
+    c->aux_off = parent->aux_off;
     c->ntt_plans = parent->ntt_plans;             // twiddle tables: immutable, owned by the root
     c->parent = root;
     root->forks.fetch_add(1);

@@ -67,6 +67,7 @@ struct zkt_ctx {
     zkt_ctx* parent = nullptr;
     std::atomic<int> forks{0};
     bool zombie = false;
+    bool aux_off = false;          // A/B builds: ZKT_NO_AUX keeps round 5's second opening on the main stream
     bool batch_off = false;        // A/B builds: ZKT_MSM_NO_BATCH commits a round's polynomials one launch sequence each
     bool lagrange_off = false;     // zkt_ctx_set_lagrange(ctx, 0): evaluations are committed through their coefficients
     std::shared_ptr<zkt::CircuitState> circuit;

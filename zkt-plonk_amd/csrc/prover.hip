@@ -86,6 +86,12 @@ struct CircuitState {
     void* pinned = nullptr;
     hipStream_t comm_stream = nullptr;   // sharded proof, asynchronous communicator: the quotient exchange's pieces travel here
     hipEvent_t ev_piece[ZKT_QUOTIENT_CHUNKS] = {}, ev_gathered = nullptr;
+    // Round 5: the second opening's polynomial work (a linear combination and a division: memory-bound) runs on this stream
+    // beside the first opening's commitment (integer-ALU bound), in buffers of its own
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
+    void* aux_scan_tmp = nullptr;
+    void* aux_pw = nullptr;
     hipStream_t copy_stream = nullptr;   // host witness uploads travel beside the main stream's work (cold path)
     hipEvent_t ev_copy[4] = {};          // a, b, c uploaded; [3]: main stream reached the upload point
     void* pinned_pi = nullptr;      // host staging of pi_tab
@@ -907,9 +913,17 @@ struct Prover {
             if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
             F zi = fe_inv_host<R>(xi);
             if ((rc = open_witness(c, comb, cap, xi.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
-            if ((rc = commit_begin(S.sc[3], cap - 1, 6))) return rc;  // the scalars are consumed by the first kernels
         }
-        {   // saw opening (prove.rs:427-451): (z1, z2, t, h1) at xi * omega
+        // saw opening (prove.rs:427-451): (z1, z2, t, h1) at xi * omega.  Its linear combination and division depend on
+        // nothing the first opening computes: on a single GPU they run on a second stream beside the first opening's
+        // commitment (memory-bound work beside an integer-ALU-bound kernel), in the z cosets' buffers, which are dead since
+        // the quotient pass.
+        const bool aux = S.aux_stream != nullptr && !c->aux_off;
+        void* comb2 = aux ? S.wcos[W_Z1] : S.sc[0];
+        void* ta2 = aux ? (void*)((char*)S.wcos[W_Z1] + cap * 32) : S.sc[1];
+        void* tb2 = aux ? (void*)((char*)S.wcos[W_Z1] + 2 * cap * 32) : S.sc[2];
+        void* out2 = aux ? S.wcos[W_Z2] : S.sc[3];
+        auto second_opening = [&]() -> int {
             LinCombArgs lo{};
             F pw = one;
             const void* ps[4] = {S.poly[6], S.poly[7], S.poly[3], S.poly[4]};
@@ -917,11 +931,27 @@ struct Prover {
                 term(lo, ps[k], cap, pw);
                 pw = fe_mul<R>(pw, eta);
             }
-            void* comb = S.sc[0];
-            if ((rc = poly_lincomb(c, lo, comb, cap))) return rc;
+            int r2;
+            if ((r2 = poly_lincomb(c, lo, comb2, cap))) return r2;
             F zi = fe_inv_host<R>(shifted);
-            if ((rc = open_witness(c, comb, cap, shifted.v, zi.v, S.sc[1], S.sc[2], S.scan_tmp, S.sc[3], S.eval_pw))) return rc;
-            if ((rc = commit_begin(S.sc[3], cap - 1, 7))) return rc;
+            return open_witness(c, comb2, cap, shifted.v, zi.v, ta2, tb2, aux ? S.aux_scan_tmp : S.scan_tmp, out2,
+                                aux ? S.aux_pw : S.eval_pw);
+        };
+        if (aux) {
+            ZKT_HIP(c, hipEventRecord(S.ev_aux_go, c->stream));
+            ZKT_HIP(c, hipStreamWaitEvent(S.aux_stream, S.ev_aux_go, 0));
+            hipStream_t main_stream = c->stream;
+            c->stream = S.aux_stream;           // the polynomial kernels launch on the context's stream
+            const int r2 = second_opening();
+            c->stream = main_stream;
+            if (r2) return r2;
+            ZKT_HIP(c, hipEventRecord(S.ev_aux_done, S.aux_stream));
+        }
+        if ((rc = commit_begin(S.sc[3], cap - 1, 6))) return rc;  // the scalars are consumed by the first kernels
+        {
+            if (aux) ZKT_HIP(c, hipStreamWaitEvent(c->stream, S.ev_aux_done, 0));
+            else if ((rc = second_opening())) return rc;
+            if ((rc = commit_begin(out2, cap - 1, 7))) return rc;
             if ((rc = msm_flush_tails(c))) return rc;
             if (S.prefetch_stage == 1) {   // ... and its round 2 keeps the GPU fed across the proof boundary
                 bool st = false;
@@ -988,6 +1018,13 @@ void circuit_release(zkt_ctx* c) {
     fr(S.fold); fr(S.qgather);
     for (void* p : S.poly_alt) fr(p);
     fr(S.status_alt);
+    fr(S.aux_scan_tmp); fr(S.aux_pw);
+    if (S.aux_stream) {
+        (void)hipStreamSynchronize(S.aux_stream);
+        (void)hipStreamDestroy(S.aux_stream);
+    }
+    if (S.ev_aux_go) (void)hipEventDestroy(S.ev_aux_go);
+    if (S.ev_aux_done) (void)hipEventDestroy(S.ev_aux_done);
     fr(S.qev); fr(S.small); fr(S.lag_scalars); fr(S.status); fr(S.lk_u32); fr(S.lk_keys); fr(S.pi_tab); fr(S.eval_pw);
     if (S.pinned) (void)hipHostFree(S.pinned);
     if (S.pinned_pi) (void)hipHostFree(S.pinned_pi);
@@ -1043,6 +1080,13 @@ static int circuit_alloc_work(zkt_ctx* c, CircuitState& S) {
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
     if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * (257 + eval_blocks)))) return rc;
+    if (S.G == 1) {
+        if ((rc = alloc(&S.aux_scan_tmp, 2 * ((n + 8) / 1024 + 4096)))) return rc;
+        if ((rc = alloc(&S.aux_pw, 2 * 257 + 8))) return rc;
+        ZKT_HIP(c, hipStreamCreateWithFlags(&S.aux_stream, hipStreamNonBlocking));
+        ZKT_HIP(c, hipEventCreateWithFlags(&S.ev_aux_go, hipEventDisableTiming));
+        ZKT_HIP(c, hipEventCreateWithFlags(&S.ev_aux_done, hipEventDisableTiming));
+    }
     return ZKT_OK;
 }
 
@@ -1383,6 +1427,7 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
         if (rc) {   // an early return may leave staged copies in flight
             (void)hipStreamSynchronize(c->circuit->copy_stream);
             if (c->circuit->comm_stream) (void)hipStreamSynchronize(c->circuit->comm_stream);
+            if (c->circuit->aux_stream) (void)hipStreamSynchronize(c->circuit->aux_stream);
             (void)hipStreamSynchronize(c->stream);
         }
     } else {
@@ -1391,6 +1436,7 @@ static int prove_impl(zkt_ctx* c, const zkt_prove_inputs* in, HostTranscript& tr
         if (rc) {
             (void)hipStreamSynchronize(c->circuit->copy_stream);
             if (c->circuit->comm_stream) (void)hipStreamSynchronize(c->circuit->comm_stream);
+            if (c->circuit->aux_stream) (void)hipStreamSynchronize(c->circuit->aux_stream);
             (void)hipStreamSynchronize(c->stream);
         }
     }
