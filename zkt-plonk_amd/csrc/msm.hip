@@ -352,7 +352,8 @@ ZKT_D uint32_t msm_bin_off(const uint32_t* offs, const uint32_t* aux, size_t i, 
 // crowded-bucket counter of this MSM (read by k_msm_bucket_sum / k_msm_heavy later on the same stream).
 __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uint32_t* aux, uint32_t nt, uint32_t nblk,
                                                        uint32_t nb1, uint32_t* bin_start, uint32_t* tile_start,
-                                                       uint2* tile_desc, uint32_t acc_threads, uint32_t B, MsmBatch bt) {
+                                                       uint2* tile_desc, uint32_t acc_threads, uint32_t B, uint32_t lanes_fold,
+                                                       MsmBatch bt) {
     __shared__ uint32_t wsum[16];
     const uint32_t y = blockIdx.y;
     offs += y * bt.s_bin_offs;
@@ -375,8 +376,10 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uin
         aux[nt] = carry;
         *heavy_count = 0;
         // the accumulation's chunk (msm.hpp MSM_CHUNK_MIN): carry = pairs with a non-zero digit
+        // lanes_fold (small keys): sixteen lanes fold a bucket's pieces, so the fold's chain is pieces / 16 + 4 additions and the
+        // balance moves to much shorter chunks: isqrt(pairs per bucket / 11) instead of isqrt(2 pairs per bucket)
         uint32_t lo = 1;
-        const uint32_t twice = 2u * (carry / B);
+        const uint32_t twice = lanes_fold ? (carry / B) / 11u : 2u * (carry / B);
         while (lo < (uint32_t)MSM_CHUNK_MIN && (lo + 1) * (lo + 1) <= twice) ++lo;
         const uint32_t even = (uint32_t)(((uint64_t)carry + acc_threads - 1) / acc_threads);
         params[0] = even > lo ? even : lo;
@@ -412,13 +415,13 @@ __global__ __launch_bounds__(1024) void k_msm_scan_aux(const uint32_t* offs, uin
 // per bin copies the bin's run to its place in `pairs`: 64 consecutive entries per instruction.
 template <class C, class PF, int DIG>
 __global__ __launch_bounds__(1024) void k_msm_bin_scatter(MsmBatch bt, int mont,
-                                                          MsmWindows win, uint32_t per_block, size_t count,
+                                                          MsmWindows win, uint32_t per_block,
                                                           uint32_t nb1, uint32_t lb, const uint32_t* offs,
                                                           const uint32_t* aux, typename PF::type* pairs) {
     using R = typename C::Fr;
     const uint32_t y = blockIdx.y;
     const Fe<R>* scalars = (const Fe<R>*)bt.scalars[y];
-    const size_t n = bt.n[y], base_off = bt.base_off[y];
+    const size_t n = bt.n[y], base_off = bt.base_off[y], count = bt.tcount[y];
     offs += y * bt.s_bin_offs;
     aux += y * bt.s_bin_aux;
     pairs = reinterpret_cast<typename PF::type*>(reinterpret_cast<char*>(pairs) + y * bt.s_pairs_bytes);
@@ -671,9 +674,10 @@ __global__ __launch_bounds__(MSM_L2S_THREADS) void k_msm_l2_scatter(const typena
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, uint32_t B, const uint32_t* chunk_bucket,
-                                                        const Affine<typename C::Fq>* table, MsmBatch bt) {
+                                                        MsmBatch bt) {
     using Q = typename C::Fq;
     const uint32_t y = blockIdx.y;
+    const Affine<Q>* table = (const Affine<Q>*)bt.table[y];
     vals += y * bt.s_vals;
     chunk_bucket += y * bt.s_chunk;
     const uint32_t* offsets = bt.offsets[y];
@@ -749,6 +753,39 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(uint32_t B, MsmTailBatch
         }
     }
     xx_store<Q>(buckets + b, acc);
+}
+
+template <class Q>
+ZKT_D XyzzX<Q> xx_shfl_down(const XyzzX<Q>& p, int delta);
+
+// The same fold by sixteen lanes per bucket (small keys, where a proof is a chain of latencies and the chip is mostly idle):
+// lane l of the group adds pieces t0 + l, t0 + l + 16, ..., then four shuffle steps; any number of pieces, no crowded-bucket
+// list.  With it the accumulation's chunks can be four pairs long instead of sixteen (k_msm_scan_aux).
+template <class C>
+__global__ __launch_bounds__(256) void k_msm_bucket_sum_lanes(uint32_t B, MsmTailBatch tb) {
+    using Q = typename C::Fq;
+    const uint32_t* offsets = tb.offsets[blockIdx.y];
+    const XyzzRaw<Q>* pieces = (const XyzzRaw<Q>*)tb.pieces[blockIdx.y];
+    Xyzz<Q>* buckets = (Xyzz<Q>*)tb.buckets[blockIdx.y];
+    const uint32_t chunk = tb.params[blockIdx.y][0];
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = g >> 4, lane = g & 15u;   // 0..B ; bucket 0 is the identity
+    XyzzX<Q> acc = xx_identity<Q>();
+    if (b >= 1 && b <= B) {
+        const uint32_t base = offsets[1];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        if (e > s) {
+            const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
+            for (uint32_t t = t0 + lane; t <= t1; t += 16) acc = xx_add<Q>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
+        }
+    }
+#pragma unroll 1
+    for (int d = 8; d >= 1; d >>= 1) {   // whole wavefronts take every step (b may exceed B in the last one: identities)
+        XyzzX<Q> o = xx_shfl_down<Q>(acc, d);
+        if ((int)lane + d >= 16) o = xx_identity<Q>();
+        acc = xx_add<Q>(acc, o);
+    }
+    if (lane == 0 && b <= B) xx_store<Q>(buckets + b, acc);
 }
 
 template <class Q>
@@ -1235,10 +1272,15 @@ static int msm_launch_tails(zkt_ctx* c) {
     ZKT_HIP(c, hipStreamWaitEvent(st.side, st.ev_main[st.tail_wait[k - 1]], 0));
     {
     ProfScope prof_fold(c, "msm_fold", st.side, (uint64_t)k);
-    hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
-    ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS, ky), dim3(256), 0, st.side, tb);
-    ZKT_HIP(c, hipGetLastError());
+    if (st.defer_tails) {   // small key: sixteen lanes per bucket, no crowded-bucket pass
+        hipLaunchKernelGGL(k_msm_bucket_sum_lanes<C>, dim3((16 * (st.B + 1) + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
+        ZKT_HIP(c, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
+        ZKT_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS, ky), dim3(256), 0, st.side, tb);
+        ZKT_HIP(c, hipGetLastError());
+    }
     }
     {
     ProfScope prof_tail(c, "msm_tail", st.side, (uint64_t)k);
@@ -1261,8 +1303,7 @@ static int msm_launch_tails(zkt_ctx* c) {
 // land in st.host_result[slots[j]] (pinned), see msm_host_finish.  k = 1 is the single MSM.
 template <class C>
 static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, const size_t* base_offs, int mont,
-                             const int* slots, int tbl = 0) {
-    using Q = typename C::Fq;
+                             const int* slots, const int* tbls) {
     MsmState& st = *c->msm;
     if (k < 1 || k > MSM_BATCH) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm batch size");
     ++c->msm_epoch;   // slot buffers change hands: anything issued ahead of time that relied on them is stale
@@ -1272,10 +1313,10 @@ static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, co
                 if (int rc0 = msm_launch_tails<C>(c)) return rc0;
     if (st.n_tail_wait + k > MSM_TAIL_BATCH)
         if (int rc0 = msm_launch_tails<C>(c)) return rc0;
-    // tbl = 1: the Lagrange-prefix table of lagrange.hip (count2 bases) instead of the key's powers
-    const void* table = tbl ? st.table2 : st.table;
-    const size_t tcount = tbl ? st.count2 : st.count;
+    // tbls[j] = 1: the Lagrange-prefix table of lagrange.hip (count2 bases) instead of the key's powers
     MsmBatch bt = st.strides;
+    bool all_lag = true;
+    for (int j = 0; j < k; ++j) all_lag = all_lag && tbls[j] != 0;
     size_t n_max = 0;
     for (int j = 0; j < MSM_BATCH; ++j) {
         const int jj = j < k ? j : 0;
@@ -1285,6 +1326,8 @@ static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, co
         bt.scalars[j] = d_scalars[jj];
         bt.n[j] = ns[jj];
         bt.base_off[j] = base_offs[jj];
+        bt.table[j] = tbls[jj] ? st.table2 : st.table;
+        bt.tcount[j] = tbls[jj] ? st.count2 : st.count;
         bt.heavy[j] = st.heavy[slot];
         bt.params[j] = st.params[slot];
         bt.offsets[j] = st.offsets[slot];
@@ -1296,7 +1339,8 @@ static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, co
     const unsigned ky = (unsigned)k;
     // (the chunk itself is computed on the device from the pairs that really exist: k_msm_scan_aux -> params[slot])
     {
-    ProfScope prof_all(c, tbl ? "msm_lag_main" : "msm_main", nullptr, (uint64_t)k);   // Lagrange-basis commitments are timed apart
+    // (Lagrange-basis commitments are timed apart: a batch that mixes both counts as dense)
+    ProfScope prof_all(c, all_lag ? "msm_lag_main" : "msm_main", nullptr, (uint64_t)k);
     {
         const uint32_t S = st.l1_scalars;
         const unsigned nblk = (unsigned)((n + S - 1) / S);
@@ -1308,21 +1352,22 @@ static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, co
         }
         hipLaunchKernelGGL(k_msm_scan_tiles, dim3(ntiles, ky), dim3(1024), 0, c->stream, st.bin_offs, total, st.bin_aux, bt);
         hipLaunchKernelGGL(k_msm_scan_aux, dim3(1, ky), dim3(1024), 0, c->stream, st.bin_offs, st.bin_aux, ntiles, nblk, st.nb1,
-                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, (uint32_t)st.acc_threads, st.B, bt);
+                           st.bin_start, st.tile_start, (uint2*)st.tile_desc, (uint32_t)st.acc_threads, st.B,
+                           st.defer_tails ? 1u : 0u, bt);
         ZKT_HIP(c, hipGetLastError());
         const size_t lds_scatter = (size_t)((3 * st.nb1 + 3) & ~3u) * 4 + (size_t)MSM_L1_CAP * (st.packed ? 4 : 8);
         const uint32_t items = (uint32_t)(m / MSM_L2_TILE + st.nb1);
         if (st.packed) {
             auto ks = msm_pick_bin_scatter<C, PairPacked>(st.dig);
             hipLaunchKernelGGL(ks, dim3(nblk, ky), dim3(1024), lds_scatter, c->stream, bt, mont, st.win, S,
-                               tcount, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
+                               st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint32_t*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
             hipLaunchKernelGGL((k_msm_l2_count<PairPacked, 8>), dim3(items, ky), dim3(256), 0, c->stream, (const uint32_t*)st.pairs,
                                st.nb1, st.lb, st.tile_start, (const uint2*)st.tile_desc, st.cnt2, bt);
         } else {
             auto ks = msm_pick_bin_scatter<C, PairWide>(st.dig);
             hipLaunchKernelGGL(ks, dim3(nblk, ky), dim3(1024), lds_scatter, c->stream, bt, mont, st.win, S,
-                               tcount, st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
+                               st.nb1, st.lb, st.bin_offs, st.bin_aux, (uint2*)st.pairs);
             ZKT_HIP(c, hipGetLastError());
             auto kc2 = st.lcols == 8 ? k_msm_l2_count<PairWide, 8> : k_msm_l2_count<PairWide, 10>;
             hipLaunchKernelGGL(kc2, dim3(items, ky), dim3(256), 0, c->stream, (const uint2*)st.pairs, st.nb1,
@@ -1351,13 +1396,13 @@ static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, co
         one.offsets[0] = bt.offsets[j];
         one.pieces[0] = bt.pieces[j];
         one.params[0] = bt.params[j];
+        one.table[0] = bt.table[j];
         {
-            ProfScope prof_acc(c, tbl ? "msm_lag_accumulate" : "msm_accumulate");
+            ProfScope prof_acc(c, tbls[j] ? "msm_lag_accumulate" : "msm_accumulate");
             // as many threads as an MSM can have chunks (threads past the last chunk leave at once)
             const uint32_t max_chunks = (uint32_t)std::min((size_t)st.W * ns[j], st.acc_threads);
             hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((max_chunks + 255) / 256, 1), dim3(256), st.acc_lds, c->stream,
-                               st.vals2 + (size_t)j * st.strides.s_vals, st.B, st.chunk_bucket + (size_t)j * st.strides.s_chunk,
-                               (const Affine<Q>*)table, one);
+                               st.vals2 + (size_t)j * st.strides.s_vals, st.B, st.chunk_bucket + (size_t)j * st.strides.s_chunk, one);
             ZKT_HIP(c, hipGetLastError());
         }
         // ---- tail on the side stream: the bucket fold (latency bound: one wave per SIMD, a few dependent additions) and
@@ -1374,7 +1419,7 @@ static int msm_enqueue_batch(zkt_ctx* c, int k, const void* const* d_scalars, co
 
 template <class C>
 static int msm_enqueue(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot = 0, int tbl = 0) {
-    return msm_enqueue_batch<C>(c, 1, &d_scalars, &n, &base_off, mont, &slot, tbl);
+    return msm_enqueue_batch<C>(c, 1, &d_scalars, &n, &base_off, mont, &slot, &tbl);
 }
 
 // S = sum_y 2^y V_y : V_y = the sum of the buckets below B whose index has bit y (y < c - 1), V_(c-1) = the top bucket.
@@ -1466,7 +1511,7 @@ int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int 
     return msm_enqueue<Bls381Curve>(c, d_scalars, n, base_off, mont, slot, tbl);
 }
 // k commitments over the key's powers as one batch (msm_enqueue_batch); slots: k distinct slots
-int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, int mont, const int* slots) {
+int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, int mont, const int* slots, const int* tbls) {
     if (!c->msm) return set_err(c, ZKT_ERR_NOT_LOADED, "no SRS loaded (zkt_srs_load)");
     if (k < 1 || k > MSM_BATCH) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm batch size");
     size_t offs[MSM_BATCH] = {};
@@ -1474,19 +1519,20 @@ int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_
         if (slots[j] < 0 || slots[j] >= MsmState::SLOTS) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "bad MSM slot");
         for (int i = 0; i < j; ++i)
             if (slots[i] == slots[j]) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "msm batch: slots must differ");
-        if (ns[j] == 0 || ns[j] > c->msm->count)
+        if (tbls[j] && !c->msm->table2) return set_err(c, ZKT_ERR_NOT_LOADED, "no Lagrange-basis table built");
+        if (ns[j] == 0 || ns[j] > (tbls[j] ? c->msm->count2 : c->msm->count))
             return set_err(c, ZKT_ERR_TOO_MANY_COEFFICIENTS, "TooManyCoefficients: polynomial longer than the committer key");
     }
-    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue_batch<Bn254Curve>(c, k, d_scalars, ns, offs, mont, slots, 0);
-    return msm_enqueue_batch<Bls381Curve>(c, k, d_scalars, ns, offs, mont, slots, 0);
+    if (c->curve == ZKT_CURVE_BN254) return msm_enqueue_batch<Bn254Curve>(c, k, d_scalars, ns, offs, mont, slots, tbls);
+    return msm_enqueue_batch<Bls381Curve>(c, k, d_scalars, ns, offs, mont, slots, tbls);
 }
 bool msm_defers_tails(const zkt_ctx* c) { return c->msm && c->msm->defer_tails; }
 // Grouping the commitments of a round as one batch of launches pays between the two regimes: below, the proof is a chain
 // of latencies (tails deferred instead); above (n = 2^20: 190 MB of grouped indices per batch) the accumulation finds the
 // indices of its own MSM evicted from the last-level cache by its neighbours' and runs 4-5 % longer, more than the grouping saves.
 bool msm_batches_grouping(const zkt_ctx* c) {
-    if (!c->msm || c->msm->defer_tails) return false;
-    size_t limit = ((size_t)1 << 18) + 64;   // measured: +1.5 % at 2^18, nothing at 2^19, -1 % at 2^20
+    if (!c->msm) return false;
+    size_t limit = MSM_DEFER_MAX;   // measured: +5 % at 2^14, +4 % at 2^16, +-1 % at 2^18, nothing at 2^19, -1 % at 2^20
     if (const char* e = exp_env("ZKT_MSM_BATCH_MAX_LOG")) limit = ((size_t)1 << atoi(e)) + 64;
     return c->msm->count <= limit;
 }

@@ -28,6 +28,8 @@ struct MsmBatch {
     const void* scalars[MSM_BATCH];
     uint64_t n[MSM_BATCH];
     uint64_t base_off[MSM_BATCH];
+    const void* table[MSM_BATCH];    // the base table each MSM runs against (the key's powers or the Lagrange-prefix table)
+    uint64_t tcount[MSM_BATCH];      // ... and its bases per window
     uint32_t* heavy[MSM_BATCH];
     uint32_t* params[MSM_BATCH];
     uint32_t* offsets[MSM_BATCH];

@@ -22,7 +22,7 @@ namespace zkt {
 // msm.hip (tbl = 1: the Lagrange-prefix table of lagrange.hip)
 int msm_g1_dev(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, uint64_t* out_xy, int* out_inf);
 int msm_begin(zkt_ctx* c, const void* d_scalars, size_t n, size_t base_off, int mont, int slot, int tbl = 0);
-int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, int mont, const int* slots);
+int msm_begin_batch(zkt_ctx* c, int k, const void* const* d_scalars, const size_t* ns, int mont, const int* slots, const int* tbls);
 int msm_flush_tails(zkt_ctx* c);           // issues the deferred bucket reductions of the commitments begun so far (small keys)
 bool msm_defers_tails(const zkt_ctx* c);
 bool msm_batches_grouping(const zkt_ctx* c);
@@ -64,7 +64,10 @@ struct CircuitState {
     void* poly[13] = {};    // a b c t h1 h2 z1 z2 pi q_lo q_mid q_hi work   (n + 8 each)
     void* wcos[W_COUNT] = {};
     void* qev = nullptr;    // 4n
-    void* lag_scalars = nullptr;   // n + 8: scalars of a commitment taken in the Lagrange basis (read by the MSM's level-1 kernels only)
+    // scalars of a commitment taken in the Lagrange basis (read by the MSM's level-1 kernels only): n + 16 each; one per
+    // commitment that may wait in the queue of a round (t, h1, h2; z2), the last also stages zkt_commit_evals_dev's blinders
+    void* lag_scalars = nullptr;
+    void* lag_scalars_q[3] = {};
     void* small = nullptr;  // blinders (19), eval partials, eval results
     uint32_t* status = nullptr;  // [0] error bits, [1] len scratch ... [4..7] quotient lens, [8..] poly lens
     uint32_t* lk_u32 = nullptr;  // lookup: perm, base counts, starts of the even half, of the odd half, hit counts
@@ -231,26 +234,63 @@ struct Prover {
         const size_t l = std::min(len, off + cnt) - off;
         return msm_begin(c, (const char*)d_poly + off * 32, l, 0, 1, slot);
     }
-    // The commitments of one round that exist at the same time (a, b, c; q_lo, q_mid, q_hi) as ONE batch of launches
-    // (msm.hip msm_enqueue_batch); a sharded key commits them one by one (each rank only its slice).
-    int commit_begin_many(void* const* d_polys, const size_t* lens, const int* slots, int k) {
-        if (c->sharded() || c->batch_off || !msm_batches_grouping(c)) {   // (msm.hip: which key sizes gain from it)
-            for (int j = 0; j < k; ++j)
-                if (int rc = commit_begin(d_polys[j], lens[j], slots[j])) return rc;
-            return ZKT_OK;
+    // Commitments wait in a queue until the round has begun them all (commit_flush), then go out in batches of up to
+    // MSM_BATCH launches-as-one (msm.hip msm_enqueue_batch: blockIdx.y = MSM, either base table per entry).  Large and sharded
+    // keys issue every commitment at once instead (msm_batches_grouping says which sizes gain).
+    struct Pending {
+        const void* scalars;
+        size_t len;
+        int slot, tbl;
+    };
+    Pending queue[6];
+    int n_queue = 0, n_lag_queued = 0;
+    bool queueing() const { return !c->sharded() && !c->batch_off && msm_batches_grouping(c); }
+    int commit_flush() {
+        int rc = ZKT_OK;
+        for (int at = 0; at < n_queue && !rc; at += 3) {
+            const int k = std::min(3, n_queue - at);
+            const void* sc[3];
+            size_t lens[3];
+            int slots[3], tbls[3];
+            for (int j = 0; j < k; ++j) {
+                sc[j] = queue[at + j].scalars; lens[j] = queue[at + j].len; slots[j] = queue[at + j].slot; tbls[j] = queue[at + j].tbl;
+            }
+            rc = msm_begin_batch(c, k, sc, lens, 1, slots, tbls);
         }
-        return msm_begin_batch(c, k, d_polys, lens, 1, slots);
+        n_queue = 0;
+        n_lag_queued = 0;
+        if (rc) return rc;
+        return msm_flush_tails(c);
+    }
+    int commit_push(const void* scalars, size_t len, int slot, int tbl) {
+        if (n_queue == 6)
+            if (int rc = commit_flush()) return rc;
+        queue[n_queue++] = Pending{scalars, len, slot, tbl};
+        return ZKT_OK;
+    }
+    int commit_begin_many(void* const* d_polys, const size_t* lens, const int* slots, int k) {
+        for (int j = 0; j < k; ++j) {
+            const int rc = queueing() ? commit_push(d_polys[j], lens[j], slots[j], 0) : commit_begin(d_polys[j], lens[j], slots[j]);
+            if (rc) return rc;
+        }
+        return ZKT_OK;
     }
     // Commitment of the polynomial with evaluations `ev` plus k blinders (prove.rs:166-180,249-251), whose blinded
     // coefficients are in d_poly.  With the Lagrange-basis table (lagrange.hip) the scalars are the differences of
     // neighbouring evaluations: for t, h1, h2 and z2 all but a few thousand of them are zero and the MSM costs next to
     // nothing; without it (sharded key, key shorter than n + 1) the coefficients are committed as the reference does.
     int commit_evals_begin(const void* ev, const void* d_poly, int blinder_off, int k, int len_slot, int slot) {
-        if (!lagrange_ready(c, S.log_n) || c->lagrange_off) return commit_begin(d_poly, S.n + (size_t)k, slot);
-        int rc = lagrange_scalars(c, ev, S.n, S.status + 8 + len_slot, (const char*)S.small + (size_t)blinder_off * 32, k, S.roots,
-                                  S.lag_scalars);
+        const bool q = queueing();
+        if (!lagrange_ready(c, S.log_n) || c->lagrange_off)
+            return q ? commit_push(d_poly, S.n + (size_t)k, slot, 0) : commit_begin(d_poly, S.n + (size_t)k, slot);
+        if (q && n_lag_queued == 3)
+            if (int rc0 = commit_flush()) return rc0;
+        void* d = q ? S.lag_scalars_q[n_lag_queued] : S.lag_scalars;   // a queued commitment keeps its scalars until the flush
+        int rc = lagrange_scalars(c, ev, S.n, S.status + 8 + len_slot, (const char*)S.small + (size_t)blinder_off * 32, k, S.roots, d);
         if (rc) return rc;
-        return msm_begin(c, S.lag_scalars, S.n + (size_t)k, 0, 1, slot, 1);
+        if (!q) return msm_begin(c, d, S.n + (size_t)k, 0, 1, slot, 1);
+        ++n_lag_queued;
+        return commit_push(d, S.n + (size_t)k, slot, 1);
     }
     // The commitments of one prover round, collected together; skip[j]: nothing was started for entry j (out[j] is left
     // alone).  Sharded: ONE all-gather of the round's partial sums (msm.hip msm_collect_sharded).
@@ -525,7 +565,7 @@ struct Prover {
                 if ((rc = commit_begin_many(polys, lens, slots, 3))) return rc;
             }
         }
-        if ((rc = msm_flush_tails(c))) return rc;
+        if ((rc = commit_flush())) return rc;
         return to_coset_many({W_A, W_B, W_C});
     }
 
@@ -569,7 +609,7 @@ struct Prover {
         }
         if ((rc = commit_evals_begin(S.ev[5], S.poly[4], 6, 3, 4, 4))) return rc;
         if ((rc = commit_evals_begin(S.ev[6], S.poly[5], 9, 2, 5, 5))) return rc;
-        if ((rc = msm_flush_tails(c))) return rc;
+        if ((rc = commit_flush())) return rc;
         if (!S.t_coset_valid && !table_done) return to_coset_many({W_T, W_H1, W_H2});
         return to_coset_many({W_H1, W_H2});   // unchanged table: its coset is still resident
     }
@@ -674,9 +714,14 @@ struct Prover {
             const PolyJob jobs[2] = {{S.ev[7], S.poly[6], 11, 3, 6}, {S.sc[0], S.poly[7], 14, 3, 7}};   // z1, z2: 3 blinders each
             if ((rc = evals_to_blinded_polys(jobs, 2))) return rc;
         }
-        if ((rc = commit_begin(S.poly[6], n + 3, 0))) return rc;
+        {
+            void* const z1p[1] = {S.poly[6]};
+            const size_t z1l[1] = {n + 3};
+            static const int z1s[1] = {0};
+            if ((rc = commit_begin_many(z1p, z1l, z1s, 1))) return rc;
+        }
         if ((rc = commit_evals_begin(S.sc[0], S.poly[7], 14, 3, 7, 1))) return rc;
-        if ((rc = msm_flush_tails(c))) return rc;
+        if ((rc = commit_flush())) return rc;
         if ((rc = to_coset_many({W_Z1, W_Z2}))) return rc;
         // the public-input polynomial of round 4 (prove.rs:258-262) is challenge-free as well.  With a handful of
         // public inputs it is never built: the quotient kernel evaluates it from rotations of l1 (poly.hpp).
@@ -778,7 +823,7 @@ struct Prover {
             const size_t lens[3] = {n + 3, n + 3, n + 3};
             static const int slots[3] = {8, 9, 10};
             if ((rc = commit_begin_many(polys, lens, slots, 3))) return rc;
-            if ((rc = msm_flush_tails(c))) return rc;
+            if ((rc = commit_flush())) return rc;
         }
         if (S.has_next) {   // zkt_prove_set_next: round 1 of the next proof hides the tail of the quotient commitments
             S.has_next = false;
@@ -947,12 +992,21 @@ struct Prover {
             if (r2) return r2;
             ZKT_HIP(c, hipEventRecord(S.ev_aux_done, S.aux_stream));
         }
-        if ((rc = commit_begin(S.sc[3], cap - 1, 6))) return rc;  // the scalars are consumed by the first kernels
+        // (small and mid-size keys: both commitments as one batch, which the second witness' own buffers allow)
+        const bool both = aux && queueing();
+        if (!both && (rc = commit_begin(S.sc[3], cap - 1, 6))) return rc;  // the scalars are consumed by the first kernels
         {
             if (aux) ZKT_HIP(c, hipStreamWaitEvent(c->stream, S.ev_aux_done, 0));
             else if ((rc = second_opening())) return rc;
-            if ((rc = commit_begin(out2, cap - 1, 7))) return rc;
-            if ((rc = msm_flush_tails(c))) return rc;
+            if (both) {
+                void* const wp[2] = {S.sc[3], out2};
+                const size_t wl[2] = {cap - 1, cap - 1};
+                static const int ws[2] = {6, 7};
+                if ((rc = commit_begin_many(wp, wl, ws, 2))) return rc;
+            } else if ((rc = commit_begin(out2, cap - 1, 7))) {
+                return rc;
+            }
+            if ((rc = commit_flush())) return rc;
             if (S.prefetch_stage == 1) {   // ... and its round 2 keeps the GPU fed across the proof boundary
                 bool st = false;
                 swap_work_sets();
@@ -1019,6 +1073,7 @@ void circuit_release(zkt_ctx* c) {
     for (void* p : S.poly_alt) fr(p);
     fr(S.status_alt);
     fr(S.aux_scan_tmp); fr(S.aux_pw);
+    for (void* q : S.lag_scalars_q) fr(q);
     if (S.aux_stream) {
         (void)hipStreamSynchronize(S.aux_stream);
         (void)hipStreamDestroy(S.aux_stream);
@@ -1063,6 +1118,7 @@ static int circuit_alloc_work(zkt_ctx* c, CircuitState& S) {
     const size_t eval_blocks = (n + 8 + 2047) / 2048 + 1;
     if ((rc = alloc(&S.small, 64 + 16 * eval_blocks))) return rc;
     if ((rc = alloc(&S.lag_scalars, n + 16))) return rc;   // n + 8 scalars, then the blinders of zkt_commit_evals_dev
+    for (auto& q : S.lag_scalars_q) if ((rc = alloc(&q, n + 16))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status, 64 * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&S.status_alt, 64 * 4))) return rc;
     for (auto& p : S.poly_alt) if ((rc = alloc(&p, n + 8))) return rc;
