@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_msm_l2_scan(const uint32_t* cnt2, uint3
             const uint32_t tb = (first[k] + chunk - 1) / chunk;
             const uint32_t te = (uint32_t)(((uint64_t)first[k] + run[k] + chunk - 1) / chunk);   // one past the last chunk start inside
             uint32_t at = 256;
-            if (te - tb > 64) at = atomicAdd(&nbig, 1u);
+            if (te - tb > 8) at = atomicAdd(&nbig, 1u);   // (small keys cut a bucket into dozens of four-pair chunks)
             if (at < 256) {
                 big[at][0] = key; big[at][1] = tb; big[at][2] = te;
             } else {
