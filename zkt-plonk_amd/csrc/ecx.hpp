@@ -129,29 +129,32 @@ ZKT_HD XyzzX<Q> xx_add_mixed(const XyzzX<Q>& p, const AffineX<Q>& q) {
     return r;
 }
 
-// add-2008-s
-template <class Q>
+// add-2008-s.  INL: every product inlined (the MSM's bucket reduction: a chain of ~25 dependent additions on one wave per
+// SIMD, where an addition's latency is its instruction count and each call into the shared product costs ~60 of them)
+template <class Q, bool INL = false>
 ZKT_HD XyzzX<Q> xx_add(const XyzzX<Q>& p, const XyzzX<Q>& q) {
+    auto mul = [](const Fx<Q>& a, const Fx<Q>& b) { return INL ? fx_mul_inl<Q>(a, b) : fx_mul<Q>(a, b); };
+    auto sqr = [](const Fx<Q>& a) { return INL ? fx_sqr_inl<Q>(a) : fx_mul<Q>(a, a); };
     if (p.inf) return q;
     if (q.inf) return p;
-    const Fx<Q> u1 = fx_mul<Q>(p.x, q.zz);
-    const Fx<Q> u2 = fx_mul<Q>(q.x, p.zz);
-    const Fx<Q> s1 = fx_mul<Q>(p.y, q.zzz);
-    const Fx<Q> s2 = fx_mul<Q>(q.y, p.zzz);
+    const Fx<Q> u1 = mul(p.x, q.zz);
+    const Fx<Q> u2 = mul(q.x, p.zz);
+    const Fx<Q> s1 = mul(p.y, q.zzz);
+    const Fx<Q> s2 = mul(q.y, p.zzz);
     const Fx<Q> pp_ = fx_sub<Q, 2>(u2, u1);            // < 4p
     const Fx<Q> rr = fx_sub<Q, 2>(s2, s1);             // < 4p
-    const Fx<Q> pp = fx_sqr<Q>(pp_);
+    const Fx<Q> pp = sqr(pp_);
     if (fx_is_zero_lt2p<Q>(pp)) {
-        if (fx_is_zero_lt2p<Q>(fx_sqr<Q>(rr))) return xx_double<Q>(p);
+        if (fx_is_zero_lt2p<Q>(sqr(rr))) return xx_double<Q>(p);
         return xx_identity<Q>();
     }
-    const Fx<Q> ppp = fx_mul<Q>(pp_, pp);
-    const Fx<Q> qq = fx_mul<Q>(u1, pp);
+    const Fx<Q> ppp = mul(pp_, pp);
+    const Fx<Q> qq = mul(u1, pp);
     XyzzX<Q> r;
-    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(fx_sqr<Q>(rr), ppp), fx_dbl<Q>(qq));        // < 8p
-    r.y = fx_sub<Q, 2>(fx_mul<Q>(rr, fx_sub<Q, 8>(qq, r.x)), fx_mul<Q>(s1, ppp));  // < 4p
-    r.zz = fx_mul<Q>(fx_mul<Q>(p.zz, q.zz), pp);
-    r.zzz = fx_mul<Q>(fx_mul<Q>(p.zzz, q.zzz), ppp);
+    r.x = fx_sub<Q, 4>(fx_sub<Q, 2>(sqr(rr), ppp), fx_dbl<Q>(qq));        // < 8p
+    r.y = fx_sub<Q, 2>(mul(rr, fx_sub<Q, 8>(qq, r.x)), mul(s1, ppp));  // < 4p
+    r.zz = mul(mul(p.zz, q.zz), pp);
+    r.zzz = mul(mul(p.zzz, q.zzz), ppp);
     r.inf = false;
     return r;
 }

@@ -728,7 +728,9 @@ __global__ __launch_bounds__(256) void k_msm_accumulate(const uint32_t* vals, ui
     xx_store_raw<Q>(pieces + (size_t)t + cur, acc);
 }
 
-template <class C>
+// MSM_TAIL_INL (template parameter of the tail kernels): the bucket reduction's additions with inlined products (ecx.hpp xx_add)
+
+template <class C, bool MSM_TAIL_INL>
 __global__ __launch_bounds__(256) void k_msm_bucket_sum(uint32_t B, MsmTailBatch tb) {
     using Q = typename C::Fq;
     const uint32_t* offsets = tb.offsets[blockIdx.y];
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum(uint32_t B, MsmTailBatch
                 return;
             }
             acc = xx_load_raw<Q>(pieces + (size_t)t0 + b);
-            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xx_add<Q>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
+            for (uint32_t t = t0 + 1; t <= t1; ++t) acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
         }
     }
     xx_store<Q>(buckets + b, acc);
@@ -761,7 +763,7 @@ ZKT_D XyzzX<Q> xx_shfl_down(const XyzzX<Q>& p, int delta);
 // The same fold by sixteen lanes per bucket (small keys, where a proof is a chain of latencies and the chip is mostly idle):
 // lane l of the group adds pieces t0 + l, t0 + l + 16, ..., then four shuffle steps; any number of pieces, no crowded-bucket
 // list.  With it the accumulation's chunks can be four pairs long instead of sixteen (k_msm_scan_aux).
-template <class C>
+template <class C, bool MSM_TAIL_INL>
 __global__ __launch_bounds__(256) void k_msm_bucket_sum_lanes(uint32_t B, MsmTailBatch tb) {
     using Q = typename C::Fq;
     const uint32_t* offsets = tb.offsets[blockIdx.y];
@@ -776,14 +778,14 @@ __global__ __launch_bounds__(256) void k_msm_bucket_sum_lanes(uint32_t B, MsmTai
         const uint32_t s = offsets[b], e = offsets[b + 1];
         if (e > s) {
             const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
-            for (uint32_t t = t0 + lane; t <= t1; t += 16) acc = xx_add<Q>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
+            for (uint32_t t = t0 + lane; t <= t1; t += 16) acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
         }
     }
 #pragma unroll 1
     for (int d = 8; d >= 1; d >>= 1) {   // whole wavefronts take every step (b may exceed B in the last one: identities)
         XyzzX<Q> o = xx_shfl_down<Q>(acc, d);
         if ((int)lane + d >= 16) o = xx_identity<Q>();
-        acc = xx_add<Q>(acc, o);
+        acc = xx_add<Q, MSM_TAIL_INL>(acc, o);
     }
     if (lane == 0 && b <= B) xx_store<Q>(buckets + b, acc);
 }
@@ -803,27 +805,27 @@ ZKT_D XyzzX<Q> xx_shfl_down(const XyzzX<Q>& p, int delta) {
 }
 
 // block-wide sum of one point per thread (256 threads); result valid in thread 0.  `wsum`: 4 LDS slots.
-template <class Q>
+template <class Q, bool MSM_TAIL_INL>
 ZKT_D XyzzX<Q> block_sum_256(XyzzX<Q> acc, Xyzz<Q>* wsum) {
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
         XyzzX<Q> o = xx_shfl_down<Q>(acc, d);
         if ((threadIdx.x & 63) + d >= 64) o = xx_identity<Q>();
-        acc = xx_add<Q>(acc, o);
+        acc = xx_add<Q, MSM_TAIL_INL>(acc, o);
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) xx_store<Q>(wsum + wv, acc);
     __syncthreads();
     if (threadIdx.x == 0) {
         acc = xx_load<Q>(wsum);
-        for (int i = 1; i < 4; ++i) acc = xx_add<Q>(acc, xx_load<Q>(wsum + i));
+        for (int i = 1; i < 4; ++i) acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load<Q>(wsum + i));
     }
     __syncthreads();
     return acc;
 }
 
 // crowded buckets (skewed digit distributions): one block folds all pieces of one bucket
-template <class C>
+template <class C, bool MSM_TAIL_INL>
 __global__ __launch_bounds__(256) void k_msm_heavy(MsmTailBatch tb) {
     using Q = typename C::Fq;
     const uint32_t* offsets = tb.offsets[blockIdx.y];
@@ -839,8 +841,8 @@ __global__ __launch_bounds__(256) void k_msm_heavy(MsmTailBatch tb) {
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t t0 = (s - base) / chunk, t1 = (e - 1 - base) / chunk;
         XyzzX<Q> acc = xx_identity<Q>();
-        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xx_add<Q>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
-        acc = block_sum_256<Q>(acc, wsum);
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load_raw<Q>(pieces + (size_t)t + b));
+        acc = block_sum_256<Q, MSM_TAIL_INL>(acc, wsum);
         if (threadIdx.x == 0) xx_store<Q>(buckets + b, acc);
     }
 }
@@ -854,19 +856,19 @@ __global__ __launch_bounds__(256) void k_msm_heavy(MsmTailBatch tb) {
 // and then read every segment once per bit (14 x 8192 additions on 120 workgroups that held registers the accumulation
 // was waiting for): seven times the additions, four times the waves, ten dependent additions more.
 // ---------------------------------------------------------------------------------------------
-template <class Q>
+template <class Q, bool MSM_TAIL_INL>
 ZKT_D XyzzX<Q> wave_sum(XyzzX<Q> acc) {   // valid in lane 0
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
         XyzzX<Q> o = xx_shfl_down<Q>(acc, d);
         if ((threadIdx.x & 63) + d >= 64) o = xx_identity<Q>();
-        acc = xx_add<Q>(acc, o);
+        acc = xx_add<Q, MSM_TAIL_INL>(acc, o);
     }
     return acc;
 }
 
 // wavefront w < NI: R_w = sum_j bucket[w NJ + j];  NI <= w < NI + NJ: C_(w - NI) = sum_i bucket[i NJ + (w - NI)]
-template <class C>
+template <class C, bool MSM_TAIL_INL>
 __global__ __launch_bounds__(256) void k_msm_rowcol(uint32_t q1, uint32_t q2, MsmTailBatch tb) {
     using Q = typename C::Fq;
     const Xyzz<Q>* buckets = (const Xyzz<Q>*)tb.buckets[blockIdx.y];
@@ -877,12 +879,12 @@ __global__ __launch_bounds__(256) void k_msm_rowcol(uint32_t q1, uint32_t q2, Ms
     if (w >= NI + NJ) return;
     XyzzX<Q> acc = xx_identity<Q>();
     if (w < NI) {
-        for (uint32_t j = lane; j < NJ; j += 64) acc = xx_add<Q>(acc, xx_load<Q>(buckets + (size_t)w * NJ + j));
+        for (uint32_t j = lane; j < NJ; j += 64) acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load<Q>(buckets + (size_t)w * NJ + j));
     } else {
         const uint32_t j = w - NI;
-        for (uint32_t i = lane; i < NI; i += 64) acc = xx_add<Q>(acc, xx_load<Q>(buckets + (size_t)i * NJ + j));
+        for (uint32_t i = lane; i < NI; i += 64) acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load<Q>(buckets + (size_t)i * NJ + j));
     }
-    acc = wave_sum<Q>(acc);
+    acc = wave_sum<Q, MSM_TAIL_INL>(acc);
     if (lane == 0) xx_store<Q>(rc + w, acc);
 }
 
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(256) void k_msm_rowcol(uint32_t q1, uint32_t q2, Ms
 // y = k < q2: sum of C_j over j with bit k; y = q2 + k, k < q1: sum of R_i over i with bit k; y = q1 + q2: the top bucket
 // alone.  Written in arkworks' R form straight into pinned host memory: the host applies the weights 2^y
 // (hostec.hpp weighted_row_sum) -- the remaining ~35 dependent curve operations cost a wavefront 0.6 ms and the host 15 us.
-template <class C>
+template <class C, bool MSM_TAIL_INL>
 __global__ __launch_bounds__(64) void k_msm_weighted_rows(uint32_t q1, uint32_t q2, uint32_t B, MsmTailBatch tb) {
     using Q = typename C::Fq;
     const Xyzz<Q>* rc = (const Xyzz<Q>*)tb.rowcol[blockIdx.y];
@@ -909,10 +911,10 @@ __global__ __launch_bounds__(64) void k_msm_weighted_rows(uint32_t q1, uint32_t 
         const Xyzz<Q>* src = col ? rc + NI : rc;
         for (uint32_t q = lane; q < cnt; q += 64) {
             const uint32_t idx = ((q & ~low) << 1) | (1u << k) | (q & low);   // q with a one inserted at bit k
-            acc = xx_add<Q>(acc, xx_load<Q>(src + idx));
+            acc = xx_add<Q, MSM_TAIL_INL>(acc, xx_load<Q>(src + idx));
         }
     }
-    acc = wave_sum<Q>(acc);
+    acc = wave_sum<Q, MSM_TAIL_INL>(acc);
     if (lane == 0) xx_store_ark<Q>(partials + y, acc);
 }
 
@@ -1251,8 +1253,8 @@ static int srs_generate_t(zkt_ctx* c, const uint64_t* tau4, size_t count, size_t
 
 // The bucket fold and reduction of every slot in st.tail_wait as ONE sequence of four launches (blockIdx.y = slot), behind
 // the accumulation of the last of them.
-template <class C>
-static int msm_launch_tails(zkt_ctx* c) {
+template <class C, bool TI>
+static int msm_launch_tails_t(zkt_ctx* c) {
     MsmState& st = *c->msm;
     const int k = st.n_tail_wait;
     if (k == 0) return ZKT_OK;
@@ -1273,12 +1275,12 @@ static int msm_launch_tails(zkt_ctx* c) {
     {
     ProfScope prof_fold(c, "msm_fold", st.side, (uint64_t)k);
     if (st.defer_tails) {   // small key: sixteen lanes per bucket, no crowded-bucket pass
-        hipLaunchKernelGGL(k_msm_bucket_sum_lanes<C>, dim3((16 * (st.B + 1) + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
+        hipLaunchKernelGGL((k_msm_bucket_sum_lanes<C, TI>), dim3((16 * (st.B + 1) + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
         ZKT_HIP(c, hipGetLastError());
     } else {
-        hipLaunchKernelGGL(k_msm_bucket_sum<C>, dim3((st.B + 1 + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
+        hipLaunchKernelGGL((k_msm_bucket_sum<C, TI>), dim3((st.B + 1 + 255) / 256, ky), dim3(256), 0, st.side, st.B, tb);
         ZKT_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(k_msm_heavy<C>, dim3(MSM_HEAVY_BLOCKS, ky), dim3(256), 0, st.side, tb);
+        hipLaunchKernelGGL((k_msm_heavy<C, TI>), dim3(MSM_HEAVY_BLOCKS, ky), dim3(256), 0, st.side, tb);
         ZKT_HIP(c, hipGetLastError());
     }
     }
@@ -1286,15 +1288,24 @@ static int msm_launch_tails(zkt_ctx* c) {
     ProfScope prof_tail(c, "msm_tail", st.side, (uint64_t)k);
     const uint32_t q = (uint32_t)(st.c - 1), q2 = q / 2, q1 = q - q2;   // 2^q buckets below B = 2^q1 rows x 2^q2 columns
     const uint32_t sums = (1u << q1) + (1u << q2);
-    hipLaunchKernelGGL(k_msm_rowcol<C>, dim3((sums + 3) / 4, ky), dim3(256), 0, st.side, q1, q2, tb);
+    hipLaunchKernelGGL((k_msm_rowcol<C, TI>), dim3((sums + 3) / 4, ky), dim3(256), 0, st.side, q1, q2, tb);
     ZKT_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(k_msm_weighted_rows<C>, dim3(q + 1, ky), dim3(64), 0, st.side, q1, q2, st.B, tb);
+    hipLaunchKernelGGL((k_msm_weighted_rows<C, TI>), dim3(q + 1, ky), dim3(64), 0, st.side, q1, q2, st.B, tb);
     ZKT_HIP(c, hipGetLastError());
     }
     // the ny + 1 row sums are written straight into pinned host memory (16 posted writes of 128 B; a copy engine took
     // ~90 us for them): the host finishes the reduction (msm_host_finish) once ev_done has fired
     for (int j = 0; j < k; ++j) ZKT_HIP(c, hipEventRecord(st.ev_done[st.tail_wait[j]], st.side));
     return ZKT_OK;
+}
+
+// Inlined products in the tail's additions pay where the tail is the critical path (small keys); on larger keys the tail runs
+// beside the next accumulation and its longer code costs more than its shorter chains give (A/B in docs/EXPERIMENTS.md).
+template <class C>
+static int msm_launch_tails(zkt_ctx* c) {
+    bool inl = c->msm->defer_tails;
+    if (const char* e = exp_env("ZKT_MSM_TAIL_INL")) inl = atoi(e) != 0;
+    return inl ? msm_launch_tails_t<C, true>(c) : msm_launch_tails_t<C, false>(c);
 }
 
 // Enqueues k <= MSM_BATCH MSMs over the same table as ONE batch: every grouping kernel and the accumulation go out once,
