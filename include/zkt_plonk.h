@@ -62,8 +62,8 @@ void zkt_ctx_destroy(zkt_ctx* ctx);
  * table, the circuit's keys (ProverKey polynomials, ExtendedProverKey cosets), the transform twiddles -- and owns only
  * what a proof writes: its stream, work buffers and MSM slots (about 3 of the ~7 GiB a context holds at n = 2^20).  For a
  * service that keeps several proofs in flight on one GPU (one host thread per context), which is what hides the latency
- * chain of the reference's real circuit sizes: n = 2^14 309 -> 460 proofs/s, n = 2^18 155 -> 177 with two or three
- * contexts.  The fork proves exactly as `ctx` would (same bytes).  Rules: no communicator on either side; while forks are
+ * chain of the reference's real circuit sizes: n = 2^14 385 -> 587 proofs/s with two contexts, n = 2^18 156 -> 186 with
+ * three.  The fork proves exactly as `ctx` would (same bytes).  Rules: no communicator on either side; while forks are
  * alive `ctx` refuses zkt_srs_* / zkt_circuit_* / zkt_ctx_set_comm (its tables are in use), and zkt_ctx_destroy(ctx) takes
  * effect when the last fork is destroyed; a fork that loads a key or circuit of its own simply stops sharing that part.
  * Create and destroy contexts from one thread (or serialise those calls); prove on them concurrently. */
