@@ -461,6 +461,20 @@ int zkt_keyfile_prover_key(const char* path, int curve_id, uint64_t* const* out_
  * zkt_transcript_seed order with their infinity flags. */
 int zkt_keyfile_verifier_key(const char* path, int curve_id, uint64_t* n, uint64_t* pi_roots_mont, size_t pi_cap, size_t* n_pi,
                              uint64_t* commitments_xy_mont, int* is_infinity10);
+/* --epk (bin/src/main.rs:34-35,108-109): ExtendedProverKey<F> (keys/mod.rs:148-174) = seventeen Vec<F> in declaration
+ * order: arith { q_m_coset q_l_coset q_r_coset q_o_coset q_c_coset }, lookup { q_lookup q_lookup_coset q_table_coset },
+ * perm { sigma1 sigma1_coset sigma2 sigma2_coset sigma3 sigma3_coset x_coset }, zh_coset, l_1_coset (4n values each, n
+ * for q_lookup and the three sigma vectors).  This library never NEEDS the file: zkt_circuit_load derives the extended
+ * key from the ProverKey on the device in milliseconds, where the file of an n = 2^20 circuit holds 1.9 GB.  It is read
+ * so that a file the reference wrote can be checked against that derivation.
+ * zkt_keyfile_extended_prover_key: the seventeen lengths, and vector `which` (0 .. 16; -1: lengths only) as Montgomery
+ * limbs into out_mont (cap elements); streamed, nothing else is held in memory.
+ * zkt_circuit_check_epk_file: every vector of the file against the loaded circuit's own extended key, recomputed on the
+ * device.  *first_mismatch_vector = -1: identical; otherwise the vector (0 .. 16) and *mismatch_at the first differing
+ * element, or (size_t)-1 when the vector's length is not this circuit's.  Unsharded contexts only; not during a proof. */
+#define ZKT_EPK_VECTORS 17
+int zkt_keyfile_extended_prover_key(const char* path, int curve_id, int which, uint64_t* out_mont, size_t cap, size_t* lens17);
+int zkt_circuit_check_epk_file(zkt_ctx* ctx, const char* epk_path, int* first_mismatch_vector, size_t* mismatch_at);
 /* the two loads a prover service does at start-up, straight from the CLI's files */
 int zkt_srs_load_file(zkt_ctx* ctx, const char* ck_path, size_t max_powers);
 int zkt_circuit_load_file(zkt_ctx* ctx, const char* pk_path, int log_n);

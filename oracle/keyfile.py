@@ -70,3 +70,23 @@ def verifier_key_bytes(cv: Curve, vk: P.VerifierKey) -> bytes:
     """plonk-core VerifierKey (keys/mod.rs:180-210): n, pi_roots, then the ten commitments."""
     out = _u64(vk.n) + _u64(len(vk.pi_roots)) + b"".join(_fr(cv, r) for r in vk.pi_roots)
     return out + b"".join(_g1_unchecked(cv, vk.commits[k]) for k in P.PK_POLYS)
+
+
+EPK_ORDER = ("q_m_coset", "q_l_coset", "q_r_coset", "q_o_coset", "q_c_coset", "q_lookup", "q_lookup_coset", "q_table_coset",
+             "sigma1", "sigma1_coset", "sigma2", "sigma2_coset", "sigma3", "sigma3_coset", "x_coset", "zh_coset", "l_1_coset")
+
+
+def extended_prover_key_vectors(epk: P.ExtendedProverKey) -> Dict[str, Sequence[int]]:
+    """The seventeen Vec<F> of plonk-core's ExtendedProverKey<F> by field name (keys/mod.rs:148-174; keys/arithmetic.rs:51-62,
+    keys/lookup.rs:70-77, keys/permutation.rs:74-92)."""
+    out = {k + "_coset": epk.cosets[k] for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "q_lookup", "q_table", "sigma1", "sigma2",
+                                                 "sigma3", "x", "zh", "l_1")}
+    out.update(q_lookup=epk.q_lookup, sigma1=epk.sigma1, sigma2=epk.sigma2, sigma3=epk.sigma3)
+    return out
+
+
+def extended_prover_key_bytes(cv: Curve, epk: P.ExtendedProverKey) -> bytes:
+    """ExtendedProverKey<F> as `serialize_to_file` writes it (bin/src/main.rs:108-109): the derive walks the fields in
+    declaration order -- arith, lookup, perm, zh_coset, l_1_coset -- and every one is a Vec<F>."""
+    vecs = extended_prover_key_vectors(epk)
+    return b"".join(_u64(len(vecs[k])) + b"".join(_fr(cv, v) for v in vecs[k]) for k in EPK_ORDER)

@@ -71,6 +71,10 @@ extern "C" {
     pub fn zkt_lagrange_info(ctx: *mut ZktCtx, log_n: *mut c_int, bases: *mut usize) -> c_int;
     pub fn zkt_circuit_load(ctx: *mut ZktCtx, log_n: c_int, pk_polys: *const *const u64, pk_lens: *const usize) -> c_int;
     pub fn zkt_circuit_load_file(ctx: *mut ZktCtx, pk_path: *const c_char, log_n: c_int) -> c_int;
+    pub fn zkt_keyfile_extended_prover_key(path: *const c_char, curve_id: c_int, which: c_int, out_mont: *mut u64, cap: usize,
+                                           lens17: *mut usize) -> c_int;
+    pub fn zkt_circuit_check_epk_file(ctx: *mut ZktCtx, epk_path: *const c_char, first_mismatch_vector: *mut c_int,
+                                      mismatch_at: *mut usize) -> c_int;
     pub fn zkt_circuit_setup(ctx: *mut ZktCtx, log_n: c_int, evals: *const *const u64, eval_lens: *const usize,
                              evals_on_device: c_int, out_commitments: *mut u64, out_is_infinity: *mut c_int) -> c_int;
     pub fn zkt_prove_with(ctx: *mut ZktCtx, inputs: *const ZktProveInputs, transcript: *const ZktTranscriptVtable,

@@ -724,6 +724,53 @@ def test_prove_from_the_reference_cli_key_files(cv, ctxs, tmp_path):
 
 
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_epk_file_of_the_reference_cli_against_the_device_derivation(cv, ctxs, tmp_path):
+    """SURVEY.md 8f.2, --epk (bin/src/main.rs:34-35,108-109): the library derives the ExtendedProverKey on the device
+    (keys/mod.rs:78-146) and never reads the file; zkt_circuit_check_epk_file says whether a file the reference wrote holds
+    the same seventeen vectors.  The file comes from the oracle's writer ("parity unpinned": the reference holds no key file)."""
+    import zkt_plonk_amd as z
+    from oracle import keyfile as KF
+    ctx = ctxs[cv.name]
+    cs = P.synthetic_circuit(cv, 1500, 64, seed=405)
+    n = cs.circuit_bound()
+    srs_arr = K.srs_mont(cv, 0xE9C, n + 8)
+    be = K.CBackend(cv, srs_arr)
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    (tmp_path / "pk").write_bytes(KF.prover_key_bytes(cv, pk))
+    blob = KF.extended_prover_key_bytes(cv, epk)
+    f = tmp_path / "epk"
+    f.write_bytes(blob)
+    ctx.srs_load(srs_arr)
+    ctx.circuit_load_file(str(tmp_path / "pk"), n.bit_length() - 1)
+    assert ctx.check_epk_file(str(f)) is None
+    # one value changed in every kind of vector: a coset, an evaluation vector, x, zh, l_1 -- found where it is
+    starts, off = [], 0
+    vecs = KF.extended_prover_key_vectors(epk)
+    for name in KF.EPK_ORDER:
+        starts.append(off + 8)
+        off += 8 + 32 * len(vecs[name])
+    for vec, at in ((0, 0), (3, 4 * n - 1), (5, 7), (8, n - 1), (13, 70001 % (4 * n)), (14, 2), (15, 4 * n - 3), (16, 65536 % (4 * n))):
+        b = bytearray(blob)
+        b[starts[vec] + 32 * at] ^= 1
+        f.write_bytes(bytes(b))
+        assert ctx.check_epk_file(str(f)) == (vec, at)
+    # the key of another circuit size: the first vector's length says so; a file that is not one: an error
+    cs2 = P.synthetic_circuit(cv, 100, 16, seed=406)
+    n2 = cs2.circuit_bound()
+    be2 = K.CBackend(cv, srs_arr[:n2 + 8])
+    pk2, epk2, vk2 = P.setup(be2, [None] * (n2 + 8), cs2, True)
+    f.write_bytes(KF.extended_prover_key_bytes(cv, epk2))
+    assert ctx.check_epk_file(str(f)) == (0, -1)
+    f.write_bytes(blob[:-5])
+    with pytest.raises(z.ZktError):
+        ctx.check_epk_file(str(f))
+    # the circuit still proves after the check borrowed its work buffers
+    blinders = field_elems(cv.fr.p, 62, P.NUM_BLINDERS)
+    want = P.prove(be, [None] * (n + 8), pk, epk, vk, cs, P.new_seeded_transcript(cv, vk), blinders).serialize(cv)
+    assert _gpu_prove(z, ctx, cv, cs, pk, vk, srs_arr, blinders) == want
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
 def test_gpu_proof_through_the_product_verifier(cv, ctxs):
     """Prover and verifier of the same library: a GPU proof goes through zkt_verify_prepare (proof.rs:285-503 without
     the pairings) and the resulting pairs satisfy L == tau W under the test trapdoor, i.e. e(L, h) == e(W, tau h)."""

@@ -94,8 +94,8 @@ def test_grand_products_and_opening_witness_alone(cv, gates, table_size):
         assert np.array_equal(z2, want2)
         runs = 1 + int(np.count_nonzero(np.any(want2[1:] != want2[:-1], axis=1)))
         assert runs <= 4 * (len(cs.table) + n // 16 + 2)                  # piecewise constant: what makes its commitment cheap
-        # the witness polynomial of an opening, full length and a short one
-        for ln in (n + 3, 5, 2):
+        # the witness polynomial of an opening: full length, lengths either side of a workgroup's 512 elements, short ones
+        for ln in sorted({l for l in (n + 3, n + 8, n // 2 + 1, 1025, 513, 512, 5, 2) if l <= n + 8}):
             poly = K.fr_to_mont(cv, field_elems(p, 900 + ln, ln))
             zz = K.fr_to_mont(cv, field_elems(p, 901, 1))[0]
             assert np.array_equal(ctx.debug_open_witness(poly, zz), K.div_linear(cv, poly, zz))

@@ -1,4 +1,4 @@
-"""f2: the readers for the reference CLI's --ck / --pk / --vk files against the oracle's writers
+"""f2: the readers for the reference CLI's --ck / --pk / --vk / --epk files against the oracle's writers
 (oracle/keyfile.py).  "Parity unpinned": the reference holds no key file; what is pinned is the round trip and the
 rejection of malformed files.  Host only."""
 import os
@@ -46,6 +46,37 @@ def test_committer_prover_and_verifier_key_round_trip(cv, tmp_path):
         assert (None if inf[k] else K.points_from_mont(cv, commits[k:k + 1])[0]) == want_pt, name
 
 
+@pytest.mark.parametrize("cv", [F.BN254, F.BLS12_381], ids=lambda c: c.name)
+def test_extended_prover_key_round_trip_and_rejections(cv, tmp_path):
+    """--epk (bin/src/main.rs:108-109): the seventeen vectors of ExtendedProverKey<F> (keys/mod.rs:148-174) come back one at
+    a time as the oracle's extend_prover_key made them; a truncated file, trailing bytes, a length beyond the file and a
+    value that is not below the modulus are refused."""
+    cs = P.test_circuit(cv)
+    n = cs.circuit_bound()
+    be = K.CBackend(cv, K.srs_mont(cv, 0xF11E, n + 8))
+    pk, epk, vk = P.setup(be, [None] * (n + 8), cs, True)
+    vecs = KF.extended_prover_key_vectors(epk)
+    blob = KF.extended_prover_key_bytes(cv, epk)
+    assert len(blob) == 17 * 8 + 32 * (13 * 4 * n + 4 * n)
+    f = tmp_path / "epk.bin"
+    f.write_bytes(blob)
+    lens, none = _lib.keyfile_extended_prover_key(str(f), cv.name)
+    assert none is None and lens == [len(vecs[k]) for k in KF.EPK_ORDER]
+    for i, name in enumerate(KF.EPK_ORDER):
+        lens, got = _lib.keyfile_extended_prover_key(str(f), cv.name, i)
+        assert K.fr_from_mont(cv, got) == [v % cv.fr.p for v in vecs[name]], name
+    # zh_coset takes four values, x_coset is g * w^i: the writer's input is what keys/mod.rs:110-117 says
+    assert len(set(vecs["zh_coset"])) == 4
+    bad = tmp_path / "bad.bin"
+    for mutate in (lambda b: b[:-1], lambda b: b + b"\x00", lambda b: b"\xff" * 8 + b[8:],
+                   lambda b: b[:8] + b"\xff" * 32 + b[40:]):
+        bad.write_bytes(mutate(blob))
+        with pytest.raises(_lib.ZktError):
+            _lib.keyfile_extended_prover_key(str(bad), cv.name, 0)
+    with pytest.raises(_lib.ZktError):
+        _lib.keyfile_extended_prover_key(str(tmp_path / "missing.bin"), cv.name)
+
+
 def test_malformed_key_files_are_rejected(tmp_path):
     cv = F.BN254
     cs, n, srs, pk, vk = _setup(cv)
@@ -81,10 +112,13 @@ def test_readers_and_verifier_survive_mutated_inputs(tmp_path):
     cv = F.BN254
     cs, n, srs, pk, vk = _setup(cv)
     rnd = random.Random(1234)
+    be0 = K.CBackend(cv, srs[:n + 8])
+    pk0, epk0, vk0 = P.setup(be0, [None] * (n + 8), P.synthetic_circuit(cv, 5, 2, seed=1), True)
     blobs = {"pk": KF.prover_key_bytes(cv, pk), "vk": KF.verifier_key_bytes(cv, vk),
-             "ck": KF.committer_key_bytes(cv, K.points_from_mont(cv, srs[:40]))}
+             "ck": KF.committer_key_bytes(cv, K.points_from_mont(cv, srs[:40])), "epk": KF.extended_prover_key_bytes(cv, epk0)}
     readers = {"pk": lambda p: _lib.keyfile_prover_key(p, cv.name), "vk": lambda p: _lib.keyfile_verifier_key(p, cv.name),
-               "ck": lambda p: _lib.keyfile_committer_key(p, cv.name, max_powers=rnd.choice([0, 1, 7, 40, 1000]))}
+               "ck": lambda p: _lib.keyfile_committer_key(p, cv.name, max_powers=rnd.choice([0, 1, 7, 40, 1000])),
+               "epk": lambda p: _lib.keyfile_extended_prover_key(p, cv.name, rnd.randrange(-1, 17))}
 
     def mutate(b):
         b = bytearray(b)
@@ -104,7 +138,7 @@ def test_readers_and_verifier_survive_mutated_inputs(tmp_path):
     outcomes = {"ok": 0, "err": 0}
     f = tmp_path / "m.bin"
     for i in range(240):
-        name = ("pk", "vk", "ck")[i % 3]
+        name = ("pk", "vk", "ck", "epk")[i % 4]
         f.write_bytes(mutate(blobs[name]))
         try:
             readers[name](str(f))

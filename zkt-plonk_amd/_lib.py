@@ -185,6 +185,26 @@ def keyfile_prover_key(path: str, curve):
     return [a[:lens[k]] for k, a in enumerate(arrs)]
 
 
+def keyfile_extended_prover_key(path: str, curve, which: int = -1):
+    """--epk file -> the seventeen vector lengths, and vector `which` as (len, 4) Montgomery limbs (host only, streamed)."""
+    L = lib()
+    cid = curve_id(curve)
+    P64 = ctypes.POINTER(ctypes.c_uint64)
+    L.zkt_keyfile_extended_prover_key.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, P64, ctypes.c_size_t,
+                                                  ctypes.POINTER(ctypes.c_size_t)]
+    lens = (ctypes.c_size_t * 17)()
+    rc = L.zkt_keyfile_extended_prover_key(path.encode(), cid, -1, None, 0, lens)
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_extended_prover_key(%s)" % path)
+    if which < 0:
+        return list(lens), None
+    out = np.zeros((max(lens[which], 1), 4), dtype=np.uint64)
+    rc = L.zkt_keyfile_extended_prover_key(path.encode(), cid, which, u64p(out), lens[which], lens)
+    if rc:
+        raise ZktError(rc, "zkt_keyfile_extended_prover_key(%s, %d)" % (path, which))
+    return list(lens), out[:lens[which]]
+
+
 def keyfile_verifier_key(path: str, curve):
     """--vk file -> (n, pi_roots (k, 4), commitments (10, 2*fq_limbs), is_infinity (10,)); Montgomery limbs (host only)."""
     L = lib()
@@ -896,6 +916,17 @@ class Context:
                                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         self.check(self._L.zkt_debug_grand_products(self._h, u64p(ch), ptrs, u64p(z1), u64p(z2)))
         return z1, z2
+
+    def check_epk_file(self, path: str):
+        """zkt_circuit_check_epk_file: None when every vector of the reference CLI's --epk file equals the loaded circuit's
+        extended key as the device derives it, else (vector 0..16, first differing element or -1 for a wrong length)."""
+        self._L.zkt_circuit_check_epk_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int),
+                                                       ctypes.POINTER(ctypes.c_size_t)]
+        vec, at = ctypes.c_int(0), ctypes.c_size_t(0)
+        self.check(self._L.zkt_circuit_check_epk_file(self._h, path.encode(), ctypes.byref(vec), ctypes.byref(at)))
+        if vec.value < 0:
+            return None
+        return vec.value, (-1 if at.value == ctypes.c_size_t(-1).value else at.value)
 
     def debug_open_witness(self, coeffs, z) -> np.ndarray:
         """(p(X) - p(z)) / (X - z) (zkt_debug_open_witness): coeffs (len, 4), z (4,), Montgomery words."""

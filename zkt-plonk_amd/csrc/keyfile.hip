@@ -3,6 +3,9 @@
 //   * the SonicKZG10 CommitterKey  (bin/src/main.rs:105 --ck)   -> powers_of_g           -> zkt_srs_load
 //   * plonk-core's ProverKey<F>    (bin/src/main.rs:107 --pk; keys/mod.rs:29-41)         -> zkt_circuit_load
 //   * plonk-core's VerifierKey     (bin/src/main.rs:111 --vk; keys/mod.rs:180-210)       -> zkt_transcript_seed
+//   * plonk-core's ExtendedProverKey<F> (bin/src/main.rs:34-35,108-109 --epk; keys/mod.rs:148-174): never NEEDED -- the
+//     extended key is derived on the device by zkt_circuit_load -- but read, vector by vector, so that a file the reference
+//     wrote can be checked against that derivation (zkt_circuit_check_epk_file, prover.hip)
 // Host-only code.  The byte layouts follow ark-serialize 0.3 / ark-poly-commit 0.3 (third-party crates absent from
 // /root/reference; restated from their published derive rules, no reference-held file exists to pin them against:
 // "parity unpinned", the round trip is tested against the writer of the test-side restatement):
@@ -15,7 +18,9 @@
 //   sonic_pc::CommitterKey    -> powers_of_g: Vec<G1Affine> first (the only field the prover needs)
 #include "ctx.hpp"
 #include "ec.hpp"
+#include "keyfile.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -184,6 +189,74 @@ static int verifier_key_t(const std::vector<uint8_t>& buf, uint64_t* n_out, uint
     return cur.pos == cur.len ? ZKT_OK : ZKT_ERR_INVALID_ARGUMENT;
 }
 
+
+// ---- ExtendedProverKey: seventeen Vec<F>, streamed (the file of a 2^20 circuit holds 1.9 GB) -------------------------
+bool EpkReader::open(const char* path) {
+    f = fopen(path, "rb");
+    if (!f) return false;
+    if (fseeko(f, 0, SEEK_END) != 0) return false;
+    const off_t sz = ftello(f);
+    if (sz < 0 || fseeko(f, 0, SEEK_SET) != 0) return false;
+    size = (uint64_t)sz;
+    pos = 0;
+    left = 0;
+    return true;
+}
+void EpkReader::close() {
+    if (f) fclose(f);
+    f = nullptr;
+}
+bool EpkReader::next(uint64_t* len) {
+    if (!f || left != 0 || size - pos < 8) return false;
+    uint8_t b[8];
+    if (fread(b, 1, 8, f) != 8) return false;
+    pos += 8;
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i) v |= (uint64_t)b[i] << (8 * i);
+    if (v > (size - pos) / 32) return false;   // a length beyond the file
+    left = v;
+    *len = v;
+    return true;
+}
+bool EpkReader::read(uint8_t* dst, size_t elems) {
+    if (!f || elems > left) return false;
+    if (elems && fread(dst, 32, elems, f) != elems) return false;
+    left -= elems;
+    pos += (uint64_t)elems * 32;
+    return true;
+}
+bool EpkReader::skip() {
+    if (!f) return false;
+    if (left && fseeko(f, (off_t)(left * 32), SEEK_CUR) != 0) return false;
+    pos += left * 32;
+    left = 0;
+    return true;
+}
+
+template <class R>
+static int epk_vector_t(EpkReader& rd, int which, uint64_t* out, size_t cap, size_t* lens) {
+    std::vector<uint8_t> chunk;
+    for (int k = 0; k < EPK_VECTORS; ++k) {
+        uint64_t len = 0;
+        if (!rd.next(&len)) return ZKT_ERR_INVALID_ARGUMENT;
+        lens[k] = (size_t)len;
+        if (k == which && out) {
+            if (len > cap) return ZKT_ERR_INVALID_ARGUMENT;
+            const size_t step = 1u << 16;
+            chunk.resize(step * 32);
+            for (size_t i = 0; i < (size_t)len; i += step) {
+                const size_t cnt = std::min(step, (size_t)len - i);
+                if (!rd.read(chunk.data(), cnt)) return ZKT_ERR_INVALID_ARGUMENT;
+                for (size_t j = 0; j < cnt; ++j)
+                    if (!field_from_bytes<R>(chunk.data() + 32 * j, 0, out + 4 * (i + j))) return ZKT_ERR_INVALID_ARGUMENT;
+            }
+        } else if (!rd.skip()) {
+            return ZKT_ERR_INVALID_ARGUMENT;
+        }
+    }
+    return rd.at_end() ? ZKT_OK : ZKT_ERR_INVALID_ARGUMENT;   // trailing bytes: not an ExtendedProverKey
+}
+
 }  // namespace zkt
 
 using namespace zkt;
@@ -215,6 +288,20 @@ int zkt_keyfile_verifier_key(const char* path, int curve_id, uint64_t* n, uint64
     if (!read_file(path, buf)) return ZKT_ERR_INVALID_ARGUMENT;
     if (curve_id == ZKT_CURVE_BN254) return verifier_key_t<Bn254Curve>(buf, n, pi_roots_mont, pi_cap, n_pi, commitments_xy_mont, is_infinity);
     return verifier_key_t<Bls381Curve>(buf, n, pi_roots_mont, pi_cap, n_pi, commitments_xy_mont, is_infinity);
+}
+
+int zkt_keyfile_extended_prover_key(const char* path, int curve_id, int which, uint64_t* out_mont, size_t cap, size_t* lens17) {
+    if (!path || !lens17 || which < -1 || which >= EPK_VECTORS || (curve_id != ZKT_CURVE_BN254 && curve_id != ZKT_CURVE_BLS12_381))
+        return ZKT_ERR_INVALID_ARGUMENT;
+    EpkReader rd;
+    if (!rd.open(path)) {
+        rd.close();
+        return ZKT_ERR_INVALID_ARGUMENT;
+    }
+    const int rc = curve_id == ZKT_CURVE_BN254 ? epk_vector_t<Bn254Fr>(rd, which, out_mont, cap, lens17)
+                                               : epk_vector_t<Bls381Fr>(rd, which, out_mont, cap, lens17);
+    rd.close();
+    return rc;
 }
 
 int zkt_srs_load_file(zkt_ctx* c, const char* ck_path, size_t max_powers) {

@@ -474,33 +474,65 @@ __global__ void k_quot_blind(Fe<P>* lo, Fe<P>* mid, Fe<P>* hi, const uint32_t* l
 // opening witness
 // ---------------------------------------------------------------------------------------------
 constexpr int PW_E = 8;
-constexpr int PW_SEG = 256 * PW_E;
-// pw[0][t] = z^t, pw[1][t] = zinv^t, t = 0..256 (two rows of EV_PW)
+// The division by (X - z) is a chain of latencies on a stream that waits for it (two scalings around a scan), not a load: the
+// workgroups are short (512 elements at the sizes the prover has) so that eight waves per SIMD hide a product's latency, and
+// no thread raises z to a power on its own -- the tables come from doubling rounds in one workgroup (k_pow_tables), about 28
+// dependent products in all where a per-workgroup z^base cost 30 in every launch.
+constexpr int OW_THREADS = 1024;   // k_pow_tables: two halves of 512 (z, 1/z)
+// elements per thread of k_mul_pow: 2 unless that needs more than 256 * 256 segment powers (lengths beyond 2^25)
+static inline int ow_elems(size_t len) {
+    int e = 2;
+    while ((len + (size_t)256 * e - 1) / ((size_t)256 * e) > 65536) e <<= 1;
+    return e;
+}
+static inline size_t ow_blocks(size_t len) {
+    const size_t seg = (size_t)256 * ow_elems(len);
+    return (len + seg - 1) / seg;
+}
+size_t open_witness_powers(size_t maxlen) { return 2 * (size_t)EV_PW + 2 * ow_blocks(maxlen) + 8; }
+
+// tab[0 .. cnt] = x^0 .. x^cnt: after the round with stride s the entries up to 2 s exist (tab[s + j] = tab[s] tab[j], j = 1..s).
+// Called by the whole workgroup with a uniform cnt; lt = index within the half that owns `tab`.
 template <class P>
-__global__ void k_pow_tables(Fe<P> z, Fe<P> zinv, Fe<P>* pw) {
-    const int t = threadIdx.x;
-    if (t < EV_PW) {
-        fe_store<P>(pw + t, fe_pow_u64<P>(z, (uint64_t)t));
-        fe_store<P>(pw + EV_PW + t, fe_pow_u64<P>(zinv, (uint64_t)t));
+ZKT_D void pow_rounds(Fe<P>* tab, const Fe<P>& x, int cnt, int lt) {
+    if (lt == 0) {
+        tab[0] = fe_one<P>();
+        tab[1] = x;
+    }
+    __syncthreads();
+    for (int s = 1; s < cnt; s <<= 1) {
+        for (int j = lt + 1; j <= s && s + j <= cnt; j += OW_THREADS / 2) tab[s + j] = fe_mul<P>(tab[s], tab[j]);
+        __syncthreads();
     }
 }
-// out[i] = in[i] * z^(i + shift) for i < n, zero for n <= i < cap.  One workgroup per 2048 consecutive elements, thread t
-// takes i = base + 256 j + t (coalesced): z^i = z^(base + shift) * z^t * (z^256)^j costs two products per element.
+// pw[0][t] = z^t, pw[1][t] = zinv^t, t = 0..256 (two rows of EV_PW), then blk[0][b] = z^(256 E b), blk[1][b] = zinv^(256 E b), b < nblk
 template <class P>
-__global__ __launch_bounds__(256) void k_mul_pow(const Fe<P>* in, Fe<P>* out, size_t n, size_t cap, Fe<P> z, const Fe<P>* pw,
-                                                 uint64_t shift) {
-    __shared__ Fe<P> zb;
-    const size_t base = (size_t)blockIdx.x * PW_SEG;
-    if (threadIdx.x == 0) zb = fe_pow_u64<P>(z, (uint64_t)base + shift);
-    __syncthreads();
-    const Fe<P> z256 = fe_load<P>(pw + 256);
-    Fe<P> r = fe_mul<P>(zb, fe_load<P>(pw + threadIdx.x));
+__global__ __launch_bounds__(OW_THREADS) void k_pow_tables(Fe<P> z, Fe<P> zinv, Fe<P>* pw, int nblk, int E) {
+    __shared__ Fe<P> row[2][EV_PW], seg[2][EV_PW], top[2][EV_PW];
+    const int half = threadIdx.x / (OW_THREADS / 2), lt = threadIdx.x % (OW_THREADS / 2);
+    pow_rounds<P>(row[half], half ? zinv : z, 256, lt);
+    Fe<P> y = row[half][256];                       // x^(256 E)
+    for (int e = 1; e < E; e <<= 1) y = fe_sqr<P>(y);
+    pow_rounds<P>(seg[half], y, 256, lt);
+    const int ntop = (nblk + 255) / 256;            // <= 256 (ow_elems)
+    pow_rounds<P>(top[half], seg[half][256], ntop, lt);
+    for (int t = lt; t < EV_PW; t += OW_THREADS / 2) fe_store<P>(pw + half * EV_PW + t, row[half][t]);
+    Fe<P>* blk = pw + 2 * EV_PW + (size_t)half * nblk;
+    for (int b = lt; b < nblk; b += OW_THREADS / 2) fe_store<P>(blk + b, fe_mul<P>(seg[half][b & 255], top[half][b >> 8]));
+}
+// out[i] = in[i] * x^(i + shift) for i < n, zero for n <= i < cap (shift 0 or 1).  One workgroup per 256 E consecutive elements,
+// thread t takes i = base + 256 j + t (coalesced): x^(i + shift) = blk[workgroup] * pw[t + shift] * (x^256)^j.
+template <class P>
+__global__ __launch_bounds__(256) void k_mul_pow(const Fe<P>* in, Fe<P>* out, size_t n, size_t cap, const Fe<P>* pw, const Fe<P>* blk,
+                                                 int E, int shift) {
+    const size_t base = (size_t)blockIdx.x * 256 * E;
+    Fe<P> r = fe_mul<P>(fe_load<P>(blk + blockIdx.x), fe_load<P>(pw + threadIdx.x + shift));
 #pragma unroll 1
-    for (int j = 0; j < PW_E; ++j) {
+    for (int j = 0; j < E; ++j) {
         const size_t i = base + (size_t)j * 256 + threadIdx.x;
         if (i >= cap) break;
         fe_store<P>(out + i, i < n ? fe_mul<P>(fe_load<P>(in + i), r) : fe_zero<P>());
-        r = fe_mul<P>(r, z256);
+        if (j + 1 < E) r = fe_mul<P>(r, fe_load<P>(pw + 256));
     }
 }
 
@@ -945,16 +977,18 @@ template <class P> static int open_witness_t(zkt_ctx* c, const void* p, size_t l
     // w_j = z^-(j+1) * sum_{i > j} p_i z^i: scale by z^i, suffix sums, scale by z^-(j+1)
     const Fe<P> zz = host_fe<P>(z), zi = host_fe<P>(zinv);
     Fe<P>* pw = (Fe<P>*)d_powers;
-    const unsigned blocks = (unsigned)((len + PW_SEG - 1) / PW_SEG);
-    hipLaunchKernelGGL(k_pow_tables<P>, dim3(1), dim3(320), 0, c->stream, zz, zi, pw);
-    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)p, (Fe<P>*)ta, len, len, zz,
-                       (const Fe<P>*)pw, (uint64_t)0);
+    const int E = ow_elems(len);
+    const unsigned blocks = (unsigned)ow_blocks(len);
+    const Fe<P>* blk = pw + 2 * EV_PW;
+    hipLaunchKernelGGL(k_pow_tables<P>, dim3(1), dim3(OW_THREADS), 0, c->stream, zz, zi, pw, (int)blocks, E);
+    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)p, (Fe<P>*)ta, len, len,
+                       (const Fe<P>*)pw, blk, E, 0);
     ZKT_HIP(c, hipGetLastError());
     int rc = scan_t<P, OpAdd>(c, (const Fe<P>*)ta, (Fe<P>*)tb, len, true, (Fe<P>*)scan_tmp);
     if (rc) return rc;
     // out[j] = S[j + 1] * zinv^(j + 1) for j + 1 < len, zero at j = len - 1
-    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)tb + 1, (Fe<P>*)out, len - 1, len, zi,
-                       (const Fe<P>*)pw + EV_PW, (uint64_t)1);
+    hipLaunchKernelGGL(k_mul_pow<P>, dim3(blocks), dim3(256), 0, c->stream, (const Fe<P>*)tb + 1, (Fe<P>*)out, len - 1, len,
+                       (const Fe<P>*)pw + EV_PW, blk + blocks, E, 1);
     ZKT_HIP(c, hipGetLastError());
     return ZKT_OK;
 }

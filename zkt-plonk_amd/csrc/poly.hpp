@@ -90,7 +90,8 @@ int quotient_split_blind(zkt_ctx* c, const void* q, size_t n, const void* d_b0b1
                          uint32_t* d_status);                                                   // prove.rs:287-300
 // KZG opening witness: w = p / (X - z)  (kzg10::compute_witness_polynomial)
 int open_witness(zkt_ctx* c, const void* p, size_t len, const uint32_t z[8], const uint32_t z_inv[8], void* d_tmp_a, void* d_tmp_b,
-                 void* d_scan_tmp, void* out, void* d_powers /* 2 x 257 elements of scratch */);
+                 void* d_scan_tmp, void* out, void* d_powers /* open_witness_powers(len) elements of scratch */);
+size_t open_witness_powers(size_t maxlen);   // elements: the powers of z and 1/z the two scalings read
 // table generation
 int gen_powers(zkt_ctx* c, void* out, size_t n, const uint32_t base[8], const uint32_t scale[8]);
 // Plookup sorted halves h1/h2 (lookup/multiset.rs:103-146)

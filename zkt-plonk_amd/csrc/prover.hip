@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "ec.hpp"
+#include "keyfile.hpp"
 #include "poly.hpp"
 #include "transcript.hpp"
 
@@ -1135,10 +1136,10 @@ static int circuit_alloc_work(zkt_ctx* c, CircuitState& S) {
     for (auto& e : S.ev_copy) ZKT_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ZKT_HIP(c, hipHostMalloc(&S.pinned_pi, QUOTIENT_PI_DIRECT_MAX * 40));
     if ((rc = dev_alloc(c, (void**)&S.pi_tab, QUOTIENT_PI_DIRECT_MAX * 40))) return rc;
-    if ((rc = alloc(&S.eval_pw, (size_t)EVAL_MAX * (257 + eval_blocks)))) return rc;
+    if ((rc = alloc(&S.eval_pw, std::max((size_t)EVAL_MAX * (257 + eval_blocks), open_witness_powers(n + 8))))) return rc;
     if (S.G == 1) {
         if ((rc = alloc(&S.aux_scan_tmp, 2 * ((n + 8) / 1024 + 4096)))) return rc;
-        if ((rc = alloc(&S.aux_pw, 2 * 257 + 8))) return rc;
+        if ((rc = alloc(&S.aux_pw, open_witness_powers(n + 8)))) return rc;
         ZKT_HIP(c, hipStreamCreateWithFlags(&S.aux_stream, hipStreamNonBlocking));
         ZKT_HIP(c, hipEventCreateWithFlags(&S.ev_aux_go, hipEventDisableTiming));
         ZKT_HIP(c, hipEventCreateWithFlags(&S.ev_aux_done, hipEventDisableTiming));
@@ -1393,6 +1394,104 @@ static int debug_grand_products_t(zkt_ctx* c, const uint64_t* ch, const uint64_t
     ZKT_HIP(c, hipMemcpyAsync(out_z1, S.ev[7], n * 32, hipMemcpyDeviceToHost, c->stream));
     ZKT_HIP(c, hipMemcpyAsync(out_z2, S.sc[0], n * 32, hipMemcpyDeviceToHost, c->stream));
     ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
+// A file the reference CLI wrote with --epk (bin/src/main.rs:108-109: ExtendedProverKey<F>, keys/mod.rs:148-174) against the
+// extended key this circuit's ProverKey gives on the device (keys/mod.rs:78-146 as zkt_circuit_load runs it): every vector is
+// recomputed in arkworks' own form (the resident cosets partly live in the quotient kernel's radix), turned canonical,
+// brought to the host and compared with the file's bytes as they stream by.
+template <class C>
+static int circuit_check_epk_t(zkt_ctx* c, const char* path, int* vec_out, size_t* at_out) {
+    using R = typename C::Fr;
+    using F = Fe<R>;
+    CircuitState& S = *c->circuit;
+    const size_t n = S.n, m = 4 * n;
+    const int log_n = S.log_n;
+    *vec_out = -1;
+    *at_out = 0;
+    EpkReader rd;
+    struct Closer {
+        EpkReader& r;
+        ~Closer() { r.close(); }
+    } closer{rd};
+    if (!rd.open(path)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+    void* plain = S.qev;          // 4n work buffers, free between proofs
+    void* canon = S.wcos[W_A];
+    const F one = fe_one<R>();
+    uint8_t zh4[4][32];           // zh_coset takes four values: g^n w4^(i mod 4) - 1 (keys/mod.rs:115-117)
+    {
+        const F g = fe_from_u32<R>(R::GENERATOR), w4n = root_of_unity<R>(log_n + 2);
+        const F w4 = fe_pow_u64<R>(w4n, (uint64_t)n);
+        F cur = fe_pow_u64<R>(g, (uint64_t)n);
+        for (int j = 0; j < 4; ++j) {
+            HostF<R>::to_le_bytes(fe_sub<R>(cur, one), zh4[j]);
+            cur = fe_mul<R>(cur, w4);
+        }
+    }
+    static const int pk_of[EPK_VECTORS] = {PK_QM, PK_QL, PK_QR, PK_QO, PK_QC, -1, PK_QLOOKUP, PK_QTABLE, -1, PK_S1, -1, PK_S2, -1, PK_S3,
+                                           -1, -1, -1};
+    std::vector<uint8_t> want, got;
+    const size_t step = (size_t)1 << 16;
+    got.resize(step * 32);
+    int rc;
+    for (int k = 0; k < EPK_VECTORS; ++k) {
+        uint64_t len = 0;
+        if (!rd.next(&len)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, std::string("not an ExtendedProverKey file: ") + path);
+        const bool evals = k == EPK_QLOOKUP || k == EPK_S1 || k == EPK_S2 || k == EPK_S3;
+        const size_t expect = evals ? n : m;
+        if (len != expect) {      // another circuit size: no element to point at
+            *vec_out = k;
+            *at_out = (size_t)-1;
+            return ZKT_OK;
+        }
+        if (k != EPK_ZH_C) {
+            const void* src = plain;
+            if (pk_of[k] >= 0) {
+                if ((rc = ntt_run(c, log_n + 2, 0, 1, S.pk[pk_of[k]], n, plain))) return rc;
+            } else if (k == EPK_QLOOKUP) {
+                src = S.q_lookup_ev;
+            } else if (evals) {
+                src = S.sigma_ev[k == EPK_S1 ? 0 : k == EPK_S2 ? 1 : 2];
+            } else if (k == EPK_X_C) {
+                src = S.coset[CS_X];
+            } else {              // l_1_coset = coset_fft(ifft(1, 0, ..., 0)) (keys/mod.rs:119-120)
+                F nn = fe_zero<R>();
+                nn.v[0] = (uint32_t)(n & 0xffffffffu);
+                nn.v[1] = (uint32_t)((uint64_t)n >> 32);
+                const F ninv = fe_inv_host<R>(fe_to_mont<R>(nn));
+                if ((rc = gen_powers(c, S.ev[0], n, one.v, ninv.v))) return rc;
+                if ((rc = ntt_run(c, log_n + 2, 0, 1, S.ev[0], n, plain))) return rc;
+            }
+            LinCombArgs lc{};     // times the word 1 = R^-1 as a Montgomery operand: the canonical value
+            lc.poly[0] = src;
+            lc.len[0] = expect;
+            lc.scalar[0][0] = 1;
+            lc.nterms = 1;
+            if ((rc = poly_lincomb(c, lc, canon, expect))) return rc;
+            want.resize(expect * 32);
+            ZKT_HIP(c, hipMemcpyAsync(want.data(), canon, expect * 32, hipMemcpyDeviceToHost, c->stream));
+            ZKT_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        for (size_t i = 0; i < expect; i += step) {
+            const size_t cnt = std::min(step, expect - i);
+            if (!rd.read(got.data(), cnt)) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, std::string("short read from ") + path);
+            bool same = true;
+            if (k != EPK_ZH_C) {
+                same = memcmp(want.data() + i * 32, got.data(), cnt * 32) == 0;
+            } else {
+                for (size_t j = 0; j < cnt && same; ++j) same = memcmp(zh4[(i + j) & 3], got.data() + j * 32, 32) == 0;
+            }
+            if (!same) {
+                size_t j = 0;
+                while (memcmp(k != EPK_ZH_C ? want.data() + (i + j) * 32 : zh4[(i + j) & 3], got.data() + j * 32, 32) == 0) ++j;
+                *vec_out = k;
+                *at_out = i + j;
+                return ZKT_OK;
+            }
+        }
+    }
+    if (!rd.at_end()) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, std::string("bytes after the seventeenth vector of ") + path);
     return ZKT_OK;
 }
 
@@ -1657,6 +1756,16 @@ int zkt_debug_grand_products(zkt_ctx* c, const uint64_t* challenges, const uint6
     c->circuit->prefetch_stage = 0;   // the work buffers are shared with an announced proof's early rounds
     if (c->curve == ZKT_CURVE_BN254) return debug_grand_products_t<Bn254Curve>(c, challenges, vectors, out_z1, out_z2);
     return debug_grand_products_t<Bls381Curve>(c, challenges, vectors, out_z1, out_z2);
+}
+
+int zkt_circuit_check_epk_file(zkt_ctx* c, const char* epk_path, int* first_mismatch_vector, size_t* mismatch_at) {
+    if (!c || !epk_path || !first_mismatch_vector || !mismatch_at) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    if (c->circuit->G != 1) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "a sharded context holds one class of every coset: check the file on an unsharded one");
+    (void)hipSetDevice(c->device);
+    c->circuit->prefetch_stage = 0;   // the work buffers are shared with an announced proof's early rounds
+    if (c->curve == ZKT_CURVE_BN254) return circuit_check_epk_t<Bn254Curve>(c, epk_path, first_mismatch_vector, mismatch_at);
+    return circuit_check_epk_t<Bls381Curve>(c, epk_path, first_mismatch_vector, mismatch_at);
 }
 
 // kzg10::compute_witness_polynomial alone (row a12: the division of prove.rs:381-451's aggregated polynomial by X - z)
