@@ -982,7 +982,14 @@ static int msm_setup(zkt_ctx* c, size_t count, const MsmState* share = nullptr) 
     if (cb < 8) cb = 8;
     if (lg <= 20) {
         if (cb > 18) cb = 18;
-        if (Q::N == 12 && lg == 20) cb = 19;
+        // r05 (profiles/ab_digit_width_r05.txt): BN254 wants its fifteen windows of 17 bits from n = 2^17 on (2^17 +6.4 %, 2^18 +8.2 %
+        // per proof against lg - 2), BLS12-381 n = 2^19 fifteen of 18 (+1.3 %); below that the bucket reductions dominate
+        if (Q::N == 12) {
+            if (lg == 20) cb = 19;
+            else if (lg == 19) cb = 18;
+        } else if (lg >= 17) {
+            cb = 17;
+        }
     } else if (cb > 20) {
         cb = 20;   // 2^19 buckets: the sort's limit (1024 level-1 bins x 1024 level-2 columns, wide pairs)
     }
