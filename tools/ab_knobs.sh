@@ -8,5 +8,6 @@ sweep() { # bench args, settings...
     echo "$a $e $(python tools/pick.py value roofline.avg_launch_ms int_alu.msm_main_stream_avg_ms int_alu.msm_tail_avg_ms gpu_active.main_stream_idle_ms_per_proof < gpurun_out/knob.json)"
   done
 }
-sweep "--log-n 18" "X=1" "ZKT_MSM_BATCH_MAX_LOG=18" "ZKT_MSM_TAIL_INL=1" "ZKT_MSM_OVER=1" "ZKT_MSM_OVER=3" "ZKT_MSM_DEFER=1" "ZKT_MSM_DEFER=1 ZKT_MSM_BATCH_MAX_LOG=18" "X=1"
-sweep "--log-n 17" "X=1" "ZKT_MSM_BATCH_MAX_LOG=18" "ZKT_MSM_TAIL_INL=1" "ZKT_MSM_OVER=1" "ZKT_MSM_DEFER=1" "ZKT_MSM_DEFER=1 ZKT_MSM_BATCH_MAX_LOG=18" "X=1"
+sweep "--log-n 17" "ZKT_MSM_TAIL_INL=1" "ZKT_MSM_TAIL_INL=1 ZKT_MSM_BATCH_MAX_LOG=18" "ZKT_MSM_TAIL_INL=1" "ZKT_MSM_TAIL_INL=1 ZKT_MSM_BATCH_MAX_LOG=18"
+sweep "--curve bls12_381 --log-n 17" "ZKT_MSM_CBITS=16 ZKT_MSM_TAIL_INL=1" "ZKT_MSM_CBITS=16 ZKT_MSM_TAIL_INL=1 ZKT_MSM_BATCH_MAX_LOG=18" "ZKT_MSM_CBITS=18 ZKT_MSM_TAIL_INL=1" "ZKT_MSM_CBITS=16 ZKT_MSM_TAIL_INL=1" "ZKT_MSM_CBITS=16 ZKT_MSM_TAIL_INL=1 ZKT_MSM_BATCH_MAX_LOG=18"
+sweep "--curve bls12_381 --log-n 18" "ZKT_MSM_TAIL_INL=1" "ZKT_MSM_TAIL_INL=1 ZKT_MSM_BATCH_MAX_LOG=18" "ZKT_MSM_TAIL_INL=1" "ZKT_MSM_TAIL_INL=1 ZKT_MSM_BATCH_MAX_LOG=18"

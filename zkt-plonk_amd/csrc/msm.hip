@@ -987,6 +987,7 @@ static int msm_setup(zkt_ctx* c, size_t count, const MsmState* share = nullptr) 
         if (Q::N == 12) {
             if (lg == 20) cb = 19;
             else if (lg == 19) cb = 18;
+            else if (lg == 17) cb = 16;   // sixteen windows instead of eighteen: +18 %
         } else if (lg >= 17) {
             cb = 17;
         }
@@ -1310,7 +1311,9 @@ static int msm_launch_tails_t(zkt_ctx* c) {
 // beside the next accumulation and its longer code costs more than its shorter chains give (A/B in docs/EXPERIMENTS.md).
 template <class C>
 static int msm_launch_tails(zkt_ctx* c) {
-    bool inl = c->msm->defer_tails;
+    // inlined products in the bucket reduction's additions: the deferred regime, and every key up to 2^18 powers (r05: n = 2^17
+    // +3.5 % per proof, BLS12-381 +7 %; 2^18 the main stream's idle time halves; 2^19 and 2^20 nothing)
+    bool inl = c->msm->defer_tails || c->msm->count <= MSM_TAIL_INL_MAX;
     if (const char* e = exp_env("ZKT_MSM_TAIL_INL")) inl = atoi(e) != 0;
     return inl ? msm_launch_tails_t<C, true>(c) : msm_launch_tails_t<C, false>(c);
 }
@@ -1550,9 +1553,11 @@ bool msm_defers_tails(const zkt_ctx* c) { return c->msm && c->msm->defer_tails; 
 // indices of its own MSM evicted from the last-level cache by its neighbours' and runs 4-5 % longer, more than the grouping saves.
 bool msm_batches_grouping(const zkt_ctx* c) {
     if (!c->msm) return false;
-    size_t limit = MSM_DEFER_MAX;   // measured: +5 % at 2^14, +4 % at 2^16, +-1 % at 2^18, nothing at 2^19, -1 % at 2^20
-    if (const char* e = exp_env("ZKT_MSM_BATCH_MAX_LOG")) limit = ((size_t)1 << atoi(e)) + 64;
-    return c->msm->count <= limit;
+    // measured: +5 % at 2^14, +4 % at 2^16, -2 % at 2^17, +3 % at 2^18 (with the inlined tail additions; BLS12-381 +2 %),
+    // nothing at 2^19, -1 % at 2^20
+    const size_t n = c->msm->count;
+    if (const char* e = exp_env("ZKT_MSM_BATCH_MAX_LOG")) return n <= ((size_t)1 << atoi(e)) + 64;
+    return n <= MSM_DEFER_MAX || (n > ((size_t)1 << 17) + 64 && n <= ((size_t)1 << 18) + 64);
 }
 int msm_flush_tails(zkt_ctx* c) {
     if (!c->msm) return ZKT_OK;

@@ -127,7 +127,8 @@ int msm_fork(zkt_ctx* child, const zkt_ctx* parent);
 // issues the deferred tails (no-op when none are waiting); the prover calls it behind the last commitment of a round
 int msm_flush_tails(zkt_ctx* c);
 bool msm_defers_tails(const zkt_ctx* c);
-bool msm_batches_grouping(const zkt_ctx* c);   // mid-size key: a round's commitments are grouped as one batch of launches   // small key: latency regime (tails deferred and batched, no batched grouping)
-constexpr size_t MSM_DEFER_MAX = ((size_t)1 << 16) + 64;
+bool msm_batches_grouping(const zkt_ctx* c);   // a round's commitments are grouped as one batch of launches (small keys, and 2^18)
+constexpr size_t MSM_DEFER_MAX = ((size_t)1 << 16) + 64;      // small key: latency regime (tails deferred and batched)
+constexpr size_t MSM_TAIL_INL_MAX = ((size_t)1 << 18) + 64;   // up to here the bucket reduction's additions inline their products
 
 }  // namespace zkt
