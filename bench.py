@@ -647,7 +647,7 @@ def main():
     if world > 1 and args.shard != "proofs":
         refs = [ctx.prove_prepared(preps[k], transcript()) for k in range(2)]        # this GPU alone, for the bytes
         progress = {"phase": "start"}
-        guard = leg_watchdog(rank, out, float(os.environ.get("ZKT_SHARD_LEG_TIMEOUT", "300")), progress)
+        guard = leg_watchdog(rank, out, float(os.environ.get("ZKT_SHARD_LEG_TIMEOUT", "180")), progress)
         try:
             sh = sharded_leg(z, par, dist, dev, args, fld, tau, evals_keep, vk, host_w, table, pis, gates, refs, barrier,
                              progress)
@@ -680,8 +680,9 @@ def main():
 def leg_watchdog(rank, out, seconds, progress):
     """The single-proof leg is an extra: if a rank is still inside it after `seconds` (a collective waiting for a peer that
     failed, a hung GPU), every rank's own timer ends its process.  Rank 0 first prints the headline line measured before the
-    leg, with the leg's last completed phase and collective count in its error record, and exits 0 (the headline is valid);
-    every other rank waits a few seconds for that line to get out and exits 3, so the launcher reports the stall."""
+    leg, with the leg's last completed phase and collective count in its error record; every other rank waits a few seconds
+    for that line to get out.  All exit 0: the headline is valid and the abandoned leg is in the line (and on stderr) -- a
+    non-zero exit would make the launcher discard a good measurement over an extra."""
     import threading
 
     def give_up():
@@ -695,7 +696,7 @@ def leg_watchdog(rank, out, seconds, progress):
             time.sleep(5.0)
         sys.stderr.write("bench.py rank %d: single-proof leg abandoned after %.0f s (%s)\n" % (rank, seconds, where))
         sys.stderr.flush()
-        os._exit(0 if rank == 0 else 3)
+        os._exit(0)
 
     t = threading.Timer(seconds, give_up)
     t.daemon = True
