@@ -519,6 +519,10 @@ int zkt_debug_grand_products(zkt_ctx* ctx, const uint64_t* challenges, const uin
 /* kzg10's witness polynomial alone (row a12): out[0 .. len - 1) = (p(X) - p(z)) / (X - z) for the len <= n + 8 coefficients
  * p, as the prover computes it (scaled suffix sums).  Host pointers, Montgomery words. */
 int zkt_debug_open_witness(zkt_ctx* ctx, const uint64_t* coeffs, size_t len, const uint64_t* z4, uint64_t* out);
+/* Row a13's kernels alone (linearization_poly.rs:55-121): k <= 12 polynomials (lens[j] <= n + 8 coefficients, Montgomery words),
+ * each evaluated at points[j] (out_evals: k x 4 words), and the first out_len coefficients of sum_j scalars[j] polys[j]. */
+int zkt_debug_eval_lincomb(zkt_ctx* ctx, const uint64_t* const* polys, const size_t* lens, int k, const uint64_t* points,
+                           const uint64_t* scalars, uint64_t* out_evals, uint64_t* out_lincomb, size_t out_len);
 
 #ifdef __cplusplus
 }

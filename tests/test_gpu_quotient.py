@@ -54,9 +54,10 @@ def test_quotient_kernel_equals_the_oracle_pointwise(cv, gates, table_size):
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("gates,table_size", [(100, 16), (5000, 256), (70000, 1024)])
 def test_grand_products_and_opening_witness_alone(cv, gates, table_size):
-    """Rows a8 / a9 / a12 on their own: the permutation and lookup grand products (permutation/mod.rs:181-254,
+    """Rows a8 / a9 / a12 / a13 on their own: the permutation and lookup grand products (permutation/mod.rs:181-254,
     lookup/mod.rs:94-151) on arbitrary vectors -- nothing has to satisfy anything, so a wrong term cannot hide behind a
-    ratio of one -- and the KZG witness polynomial (kzg10::compute_witness_polynomial), each against the CPU oracle
+    ratio of one -- the evaluation and linear-combination kernels of the linearisation (linearization_poly.rs:55-121) and
+    the KZG witness polynomial (kzg10::compute_witness_polynomial), each against the CPU oracle
     element by element; then the lookup product on vectors of the prover's own shape (sorted halves of a real
     combine_split), whose long runs of ratio one are what the Lagrange-basis commitment of z2 relies on."""
     import zkt_plonk_amd as z
@@ -94,6 +95,27 @@ def test_grand_products_and_opening_witness_alone(cv, gates, table_size):
         assert np.array_equal(z2, want2)
         runs = 1 + int(np.count_nonzero(np.any(want2[1:] != want2[:-1], axis=1)))
         assert runs <= 4 * (len(cs.table) + n // 16 + 2)                  # piecewise constant: what makes its commitment cheap
+        # row a13 alone: evaluations at a point each and a linear combination of polynomials of the prover's lengths
+        # (linearization_poly.rs:55-121), against Horner's rule and the plain sum on big integers
+        lens = sorted({l for l in (n + 8, n + 3, n, n // 2 + 1, 2049, 2048, 5, 1) if l <= n + 8}, reverse=True)[:7]
+        polys = [field_elems(p, 700 + i, ln) for i, ln in enumerate(lens)]
+        pts = field_elems(p, 710, len(lens))
+        pts[0] = 0                                                      # p(0) = the constant term
+        scs = field_elems(p, 711, len(lens))
+        out_len = n + 8
+        ev, lc = ctx.debug_eval_lincomb([K.fr_to_mont(cv, q) for q in polys], K.fr_to_mont(cv, pts), K.fr_to_mont(cv, scs), out_len)
+        want_ev = []
+        for q, x in zip(polys, pts):
+            acc = 0
+            for coef in reversed(q):
+                acc = (acc * x + coef) % p
+            want_ev.append(acc)
+        assert K.fr_from_mont(cv, ev) == want_ev
+        want_lc = [0] * out_len
+        for q, sc in zip(polys, scs):
+            for i, coef in enumerate(q):
+                want_lc[i] = (want_lc[i] + sc * coef) % p
+        assert K.fr_from_mont(cv, lc) == want_lc
         # the witness polynomial of an opening: full length, lengths either side of a workgroup's 512 elements, short ones
         for ln in sorted({l for l in (n + 3, n + 8, n // 2 + 1, 1025, 513, 512, 5, 2) if l <= n + 8}):
             poly = K.fr_to_mont(cv, field_elems(p, 900 + ln, ln))

@@ -928,6 +928,23 @@ class Context:
             return None
         return vec.value, (-1 if at.value == ctypes.c_size_t(-1).value else at.value)
 
+    def debug_eval_lincomb(self, polys, points, scalars, out_len: int):
+        """zkt_debug_eval_lincomb: polys: list of (len_j, 4) arrays, points / scalars (k, 4); returns (evals (k, 4), lincomb
+        (out_len, 4)).  Montgomery words throughout."""
+        keep = [np.ascontiguousarray(p_, dtype=np.uint64).reshape(-1, 4) for p_ in polys]
+        k = len(keep)
+        P64 = ctypes.POINTER(ctypes.c_uint64)
+        ptrs = (P64 * k)(*[u64p(a) for a in keep])
+        lens = (ctypes.c_size_t * k)(*[a.shape[0] for a in keep])
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(k, 4)
+        scs = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(k, 4)
+        ev = np.empty((k, 4), dtype=np.uint64)
+        lc = np.empty((out_len, 4), dtype=np.uint64)
+        self._L.zkt_debug_eval_lincomb.argtypes = [ctypes.c_void_p, ctypes.POINTER(P64), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int,
+                                                   P64, P64, P64, P64, ctypes.c_size_t]
+        self.check(self._L.zkt_debug_eval_lincomb(self._h, ptrs, lens, k, u64p(pts), u64p(scs), u64p(ev), u64p(lc), out_len))
+        return ev, lc
+
     def debug_open_witness(self, coeffs, z) -> np.ndarray:
         """(p(X) - p(z)) / (X - z) (zkt_debug_open_witness): coeffs (len, 4), z (4,), Montgomery words."""
         p_ = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)

@@ -1768,6 +1768,41 @@ int zkt_circuit_check_epk_file(zkt_ctx* c, const char* epk_path, int* first_mism
     return circuit_check_epk_t<Bls381Curve>(c, epk_path, first_mismatch_vector, mismatch_at);
 }
 
+// Row a13's two kernels alone (linearization_poly.rs:55-121): k <= 12 polynomials of the prover's lengths, each evaluated at its
+// own point (poly_eval_many), and their linear combination sum_j scalars[j] polys[j] (poly_lincomb)
+int zkt_debug_eval_lincomb(zkt_ctx* c, const uint64_t* const* polys, const size_t* lens, int k, const uint64_t* points,
+                           const uint64_t* scalars, uint64_t* out_evals, uint64_t* out_lincomb, size_t out_len) {
+    if (!c || !polys || !lens || !points || !scalars || !out_evals || !out_lincomb) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!c->circuit) return set_err(c, ZKT_ERR_NOT_LOADED, "no circuit loaded (zkt_circuit_load)");
+    CircuitState& S = *c->circuit;
+    const size_t cap = S.n + 8;
+    if (k < 1 || k > 12 || out_len < 1 || out_len > cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "1 .. 12 polynomials, out_len <= n + 8");
+    for (int j = 0; j < k; ++j)
+        if (!polys[j] || lens[j] < 1 || lens[j] > cap) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "1 .. n + 8 coefficients each");
+    (void)hipSetDevice(c->device);
+    S.prefetch_stage = 0;   // the work buffers are shared with an announced proof's early rounds
+    EvalArgs ea{};
+    LinCombArgs lc{};
+    ea.count = k;
+    lc.nterms = k;
+    for (int j = 0; j < k; ++j) {
+        ZKT_HIP(c, hipMemcpyAsync(S.poly[j], polys[j], lens[j] * 32, hipMemcpyHostToDevice, c->stream));
+        ea.poly[j] = lc.poly[j] = S.poly[j];
+        ea.len[j] = lc.len[j] = lens[j];
+        memcpy(ea.point[j], points + 4 * j, 32);
+        memcpy(lc.scalar[j], scalars + 4 * j, 32);
+    }
+    void* d_partials = (char*)S.small + 64 * 32;
+    void* d_results = (char*)S.small + 32 * 32;
+    int rc = poly_eval_many(c, ea, d_partials, d_results, S.eval_pw);
+    if (rc) return rc;
+    if ((rc = poly_lincomb(c, lc, S.sc[0], out_len))) return rc;
+    ZKT_HIP(c, hipMemcpyAsync(out_evals, d_results, (size_t)k * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipMemcpyAsync(out_lincomb, S.sc[0], out_len * 32, hipMemcpyDeviceToHost, c->stream));
+    ZKT_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKT_OK;
+}
+
 // kzg10::compute_witness_polynomial alone (row a12: the division of prove.rs:381-451's aggregated polynomial by X - z)
 int zkt_debug_open_witness(zkt_ctx* c, const uint64_t* coeffs, size_t len, const uint64_t* z4, uint64_t* out) {
     if (!c || !coeffs || !z4 || !out) return set_err(c, ZKT_ERR_INVALID_ARGUMENT, "null pointer");
