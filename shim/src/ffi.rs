@@ -71,8 +71,6 @@ extern "C" {
     pub fn zkt_lagrange_info(ctx: *mut ZktCtx, log_n: *mut c_int, bases: *mut usize) -> c_int;
     pub fn zkt_circuit_load(ctx: *mut ZktCtx, log_n: c_int, pk_polys: *const *const u64, pk_lens: *const usize) -> c_int;
     pub fn zkt_circuit_load_file(ctx: *mut ZktCtx, pk_path: *const c_char, log_n: c_int) -> c_int;
-    pub fn zkt_debug_eval_lincomb(ctx: *mut ZktCtx, polys: *const *const u64, lens: *const usize, k: c_int, points: *const u64,
-                                  scalars: *const u64, out_evals: *mut u64, out_lincomb: *mut u64, out_len: usize) -> c_int;
     pub fn zkt_keyfile_extended_prover_key(path: *const c_char, curve_id: c_int, which: c_int, out_mont: *mut u64, cap: usize,
                                            lens17: *mut usize) -> c_int;
     pub fn zkt_circuit_check_epk_file(ctx: *mut ZktCtx, epk_path: *const c_char, first_mismatch_vector: *mut c_int,
