@@ -117,7 +117,7 @@ def test_msm_edge_cases(cv, ctxs, golden):
 
 
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("log_n", [10, 14, 16])
+@pytest.mark.parametrize("log_n", [10, 14, 16, 17, 18, 19])   # every digit-width / launch regime of msm.hip below 2^20
 def test_msm_random_matches_oracle(cv, log_n, ctxs):
     ctx = ctxs[cv.name]
     n = (1 << log_n) + 5
@@ -132,14 +132,15 @@ def test_msm_random_matches_oracle(cv, log_n, ctxs):
     assert not inf and np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("log_n", [16, 17])
 @pytest.mark.parametrize("shape", ["all_equal", "small", "three_values", "sparse", "top_bits"])
-def test_msm_skewed_digit_distributions(shape, ctxs):
+def test_msm_skewed_digit_distributions(shape, log_n, ctxs):
     """The bucket grouping (two-level counting sort) and the chunked accumulation must not depend on the digits
     being uniform: a single crowded bucket per window (many level-2 tiles in one bin, the heavy-bucket fold),
     empty high windows, a handful of distinct digits, mostly-zero scalars."""
     cv = F.BN254
     ctx = ctxs[cv.name]
-    n = (1 << 16) + 321
+    n = (1 << log_n) + 321                        # 2^17: fifteen 17-bit windows, inlined reduction (r05 rules)
     ctx.srs_generate(0xD15EA5E, n)
     srs = ctx.srs_download(0, n)
     rng = np.random.default_rng(sum(map(ord, shape)))
