@@ -206,10 +206,12 @@ def _gpu_prove_arrays(z, ctx, cv, w, vk, blinders):
     return ctx.prove(w["a"], w["b"], w["c"], w["table"], w["pi_pos"], w["pi_vals"], K.fr_to_mont(cv, blinders), tr)
 
 
-@pytest.mark.parametrize("cvname,log_n", [("bn254", 14), ("bls12_381", 14), ("bn254", 20), ("bls12_381", 20)])
+@pytest.mark.parametrize("cvname,log_n", [("bn254", 14), ("bls12_381", 14), ("bn254", 17), ("bls12_381", 17), ("bn254", 18),
+                                          ("bls12_381", 18), ("bn254", 19), ("bn254", 20), ("bls12_381", 20)])
 def test_headline_configs_proof_bytes_equal_cpu_oracle(cvname, log_n, ctxs):
     """BASELINE.json configs[0] (BN254, n = 2^14) and configs[3] (BN254, n = 2^20: the workload bench.py times), plus
-    BLS12-381 at 2^14 and 2^20: the GPU proof equals, byte for byte, the proof of the CPU oracle's array prover
+    BLS12-381 at 2^14 and 2^20 and the sizes between (2^17, 2^18: the reference CLI's default feature set, 2^19: each has
+    its own MSM digit width and launch regime): the GPU proof equals, byte for byte, the proof of the CPU oracle's array prover
     (oracle/fastplonk.py, pinned to the big-integer restatement of prove.rs:59-470 in tests/test_coracle.py) on the
     same SRS, witness, public inputs and blinders.  VerifierKey commitments: all ten at 2^14, two at 2^20."""
     import zkt_plonk_amd as z
